@@ -1,0 +1,148 @@
+/*
+ * uh_hotpath.h -- C ABI of the MI355X (gfx950) hot path of "Unsupervised Deep Homography":
+ * Tensor-DLT + projective Spatial-Transformer bilinear warp + photometric L1, forward and backward.
+ *
+ * The reference (tynguyen/unsupervisedDeepHomographyRAL2018) is pure Python/TF1: it has no FFI.  The
+ * seam these entry points replace is the Python-level operator seam (paths relative to
+ * /root/reference/code/):
+ *
+ *   uh_dlt_forward / uh_dlt_backward
+ *        <- HomographyModel.solve_DLT()              homography_model.py:169-250  (+ tf autodiff of it:
+ *           MatrixSolveGrad) and the theta = M^-1 H M fold of transform()   homography_model.py:254
+ *   uh_warp_forward / uh_warp_backward
+ *        <- transformer(U, theta, out_size)          utils/tf_spatial_transformer.py:18-251
+ *           (_meshgrid :141, _transform :182, _interpolate :76) and tf autodiff of it w.r.t. theta
+ *   uh_gray_patch_forward / uh_gray_patch_backward
+ *        <- reduce_mean(axis=3) + flat gather by patch_indices + batch_indices
+ *                                                     homography_model.py:74-76,263-269
+ *   uh_l1_loss_forward / uh_l1_loss_backward
+ *        <- build_losses() l1 branch                  homography_model.py:328
+ *   uh_warp_patch_l1_fwdbwd
+ *        <- the composition of the four above restricted to the P x P loss patch
+ *
+ * Conventions
+ *   - every `const float*` / `float*` / `const int*` below is a DEVICE pointer owned by the caller,
+ *     contiguous, row-major, 4-byte aligned, unless the comment says HOST.  Images are NHWC.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); nothing synchronises, allocates or frees; no global mutable state other than the
+ *     optional profiler below; entry points are thread-safe.
+ *   - return value: 0 = ok; >0 = a hipError_t raised by the launch; <0 = argument error (UH_E_*).
+ *   - arithmetic: IEEE f32, FP contraction OFF on the forward paths so that results are op-for-op
+ *     those of the un-fused TF-CPU graph (see DESIGN.md "Numerics").
+ */
+#ifndef UH_HOTPATH_H
+#define UH_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UH_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define UH_API __attribute__((visibility("default")))
+#else
+#define UH_API
+#endif
+
+/* argument errors */
+#define UH_E_NULL        (-1)   /* a required pointer is NULL                     */
+#define UH_E_SHAPE       (-2)   /* non-positive or inconsistent dimension          */
+#define UH_E_CHANNELS    (-3)   /* C not in {1,2,3,4}                             */
+#define UH_E_WORKSPACE   (-4)   /* workspace missing or smaller than *_workspace_bytes() */
+#define UH_E_TOO_LARGE   (-5)   /* one image exceeds 2^31 bytes, or patch index range */
+
+/* flags for uh_dlt_* */
+#define UH_DLT_SOLVE_F32   0u   /* default: f32 partial-pivot LU, the tf.matrix_solve semantics  */
+#define UH_DLT_SOLVE_F64   1u   /* same algorithm carried in f64, result rounded to f32           */
+
+typedef void* uh_stream_t;     /* hipStream_t */
+
+UH_API int         uh_abi_version(void);
+UH_API const char* uh_error_string(int code);
+
+/* ---- Tensor-DLT ------------------------------------------------------------------------------
+ * pts1 [B,8] (x,y of 4 corners), h4p [B,8] (predicted corner deltas)  ->  H [B,9] row-major, h33=1.
+ * If theta != NULL also writes theta = Minv * H * M  [B,9]; M and Minv are HOST pointers to 9 floats
+ * (the constants of homography_model.py:63-72; may be NULL when theta is NULL).                  */
+UH_API int uh_dlt_forward(const float* pts1, const float* h4p, float* H, float* theta,
+                   const float* M_host, const float* Minv_host,
+                   int B, unsigned flags, uh_stream_t stream);
+
+/* Gradient w.r.t. h4p.  Exactly one of dH / dtheta must be non-NULL: with dtheta the kernel first
+ * folds dH = Minv^T dtheta M^T.  H is the forward output.                                        */
+UH_API int uh_dlt_backward(const float* pts1, const float* h4p, const float* H,
+                    const float* dH, const float* dtheta,
+                    const float* M_host, const float* Minv_host,
+                    float* dh4p, int B, unsigned flags, uh_stream_t stream);
+
+/* ---- Spatial transformer ----------------------------------------------------------------------
+ * U [B,H,W,C], theta [B,9] -> out [B,oh,ow,C].  `condition` (device float[1], may be NULL) receives
+ * sum over all samples of [|t| > 1e-7]  (tf_spatial_transformer.py:235).                          */
+UH_API int uh_warp_forward(const float* U, const float* theta, float* out, float* condition,
+                    int B, int H, int W, int C, int oh, int ow, uh_stream_t stream);
+
+UH_API size_t uh_warp_backward_workspace_bytes(int B, int H, int W, int C, int oh, int ow);
+
+/* dTheta [B,9] = d loss/d theta given dOut [B,oh,ow,C].  dU (may be NULL) receives d loss/d U
+ * [B,H,W,C] (scatter-add; the reference never requests it).  Deterministic two-stage reduction for
+ * dTheta through `workspace` (>= uh_warp_backward_workspace_bytes bytes, device, 8-byte aligned). */
+UH_API int uh_warp_backward(const float* U, const float* theta, const float* dOut,
+                     float* dTheta, float* dU, void* workspace, size_t workspace_bytes,
+                     int B, int H, int W, int C, int oh, int ow, uh_stream_t stream);
+
+/* ---- gray + patch gather ------------------------------------------------------------------------
+ * warped [B,H,W,C], patch_idx [B,PP] int32 (flat y*W+x within one image) -> pred [B,PP]
+ * pred[k,i] = mean_c warped[k, patch_idx[k,i], c]                                                  */
+UH_API int uh_gray_patch_forward(const float* warped, const int* patch_idx, float* pred,
+                          int B, int H, int W, int C, int PP, uh_stream_t stream);
+/* dWarped [B,H,W,C] is fully overwritten: zero + scatter-add of dPred/C (duplicates allowed).       */
+UH_API int uh_gray_patch_backward(const float* dPred, const int* patch_idx, float* dWarped,
+                           int B, int H, int W, int C, int PP, uh_stream_t stream);
+
+/* ---- photometric L1 -------------------------------------------------------------------------------
+ * loss[0] = mean |pred - target| over n elements.  workspace: uh_l1_loss_workspace_bytes(n).        */
+UH_API size_t uh_l1_loss_workspace_bytes(size_t n);
+UH_API int uh_l1_loss_forward(const float* pred, const float* target, float* loss, void* workspace,
+                       size_t workspace_bytes, size_t n, uh_stream_t stream);
+/* dPred = dLoss[0] * sign(pred - target) / n   (dLoss is a device scalar)                           */
+UH_API int uh_l1_loss_backward(const float* pred, const float* target, const float* dLoss, float* dPred,
+                        size_t n, uh_stream_t stream);
+
+/* ---- fused patch path ---------------------------------------------------------
+ * For the P x P loss patch only: sample -> gray -> |pred - I2| -> loss, and d loss/d theta for
+ * dLoss = 1, in ONE pass that never materialises the warped frame.
+ *   U [B,H,W,C], theta [B,9], I2 [B,PP], patch_idx [B,PP]  ->  pred [B,PP], loss[1], dTheta [B,9]
+ * dTheta may be NULL (forward only).                                                                */
+UH_API size_t uh_warp_patch_l1_workspace_bytes(int B, int PP);
+UH_API int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const float* I2,
+                            const int* patch_idx, float* pred, float* loss, float* dTheta,
+                            void* workspace, size_t workspace_bytes,
+                            int B, int H, int W, int C, int PP, uh_stream_t stream);
+
+/* ---- in-library kernel timing (used by bench.py for the roofline figure) -----------------------------
+ * When enabled, every launch above is bracketed by hipEventRecord on ITS stream; uh_profile_read()
+ * synchronises those events and accumulates per-kernel totals.  Not thread-safe while enabled.      */
+#define UH_K_DLT_FWD        0
+#define UH_K_DLT_BWD        1
+#define UH_K_WARP_FWD       2
+#define UH_K_WARP_BWD       3   /* per-tile partial kernel (the bandwidth kernel)                    */
+#define UH_K_WARP_BWD_FIN   4   /* tiny finishing reduction                                          */
+#define UH_K_GRAY_FWD       5
+#define UH_K_GRAY_BWD       6
+#define UH_K_L1_FWD         7
+#define UH_K_L1_BWD         8
+#define UH_K_PATCH_FUSED    9
+#define UH_K_PATCH_FIN     10
+#define UH_K_COUNT         11
+UH_API int uh_profile_enable(int on);                        /* returns previous state; resets counters  */
+UH_API int uh_profile_read(double* total_ms /*[UH_K_COUNT]*/, long long* launches /*[UH_K_COUNT]*/);
+UH_API const char* uh_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UH_HOTPATH_H */

@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/uh_hotpath.h
+declares, validates arguments without touching a GPU, and the product path refuses CPU tensors."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'uh_hotpath.h')).read()
+    return sorted(set(re.findall(r'^UH_API\s+[\w\s\*]+?\b(uh_\w+)\s*\(', src, flags=re.M)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for must in ('uh_dlt_forward', 'uh_dlt_backward', 'uh_warp_forward', 'uh_warp_backward',
+                 'uh_warp_backward_workspace_bytes', 'uh_warp_patch_l1_fwdbwd', 'uh_gray_patch_forward',
+                 'uh_l1_loss_forward'):
+        assert must in syms
+    assert len(syms) >= 17
+
+
+def test_library_exports_every_declared_symbol(uh_lib_path):
+    lib = C.CDLL(uh_lib_path)
+    for name in declared_symbols():
+        assert hasattr(lib, name), 'missing export: ' + name
+
+
+def test_binding_covers_header(uh_lib_path):
+    from unsuperviseddeephomographyral2018_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    lib = _lib.load()
+    assert lib.uh_abi_version() == _lib.UH_ABI_VERSION
+
+
+def test_argument_errors_without_gpu(uh_lib_path):
+    """Argument validation happens before any HIP call, so it is testable on a GPU-less host."""
+    from unsuperviseddeephomographyral2018_amd import _lib
+    lib = _lib.load()
+    one = C.c_void_p(16)     # never dereferenced: validation fails first
+    assert lib.uh_warp_forward(None, one, one, None, 1, 8, 8, 3, 8, 8, None) == -1          # UH_E_NULL
+    assert lib.uh_warp_forward(one, one, one, None, 0, 8, 8, 3, 8, 8, None) == -2           # UH_E_SHAPE
+    assert lib.uh_warp_forward(one, one, one, None, 1, 8, 8, 5, 8, 8, None) == -3           # UH_E_CHANNELS
+    assert lib.uh_warp_forward(one, one, one, None, 1, 1 << 14, 1 << 14, 3, 8, 8, None) == -5  # UH_E_TOO_LARGE
+    assert lib.uh_warp_backward(one, one, one, one, None, None, 0, 1, 8, 8, 3, 8, 8, None) == -4  # UH_E_WORKSPACE
+    assert lib.uh_dlt_forward(one, one, None, None, None, None, 4, 0, None) == -1
+    assert lib.uh_dlt_forward(one, one, one, one, None, None, 4, 0, None) == -1             # theta needs M
+    assert lib.uh_dlt_backward(one, one, one, None, None, None, None, one, 4, 0, None) == -1  # dH xor dtheta
+    assert lib.uh_dlt_backward(one, one, one, one, one, None, None, one, 4, 0, None) == -1
+    assert lib.uh_l1_loss_forward(one, one, one, None, 0, 16, None) == -4
+    assert lib.uh_warp_patch_l1_fwdbwd(one, one, one, one, one, one, None, None, 0, 1, 8, 8, 3, 16, None) == -4
+    assert lib.uh_warp_backward_workspace_bytes(64, 240, 320, 3, 240, 320) == 64 * 5 * 15 * 9 * 4
+    assert lib.uh_warp_backward_workspace_bytes(0, 240, 320, 3, 240, 320) == 0
+    assert b'UH_E_WORKSPACE' in lib.uh_error_string(-4)
+    assert lib.uh_kernel_name(2) == b'warp_forward'
+
+
+def test_product_path_refuses_cpu_tensors(uh_lib_path):
+    torch = pytest.importorskip('torch')
+    from unsuperviseddeephomographyral2018_amd import ops, _lib
+    U = torch.zeros(1, 8, 8, 3)
+    th = torch.eye(3).reshape(1, 9)
+    with pytest.raises(_lib.UHError, match='no CPU fallback'):
+        ops.transformer(U, th, (8, 8))
+    with pytest.raises(_lib.UHError, match='no CPU fallback'):
+        ops.solve_dlt(torch.zeros(1, 8), torch.zeros(1, 8))
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'unsuperviseddeephomographyral2018_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f

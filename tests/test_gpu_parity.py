@@ -1,0 +1,354 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerances (stated once, used below):
+  * forward warp / DLT vs the f32 op-order-faithful oracle on identical inputs: <= 1e-6 abs on
+    normalised images (expected bit-exact: same IEEE ops in the same order, FP contraction off);
+  * forward warp vs the f64 oracle on in-frame pixels: <= 1e-4 max-abs  (north_star tolerance);
+  * L1 loss: <= 1e-4 abs (north_star), observed ~1e-7;
+  * gradients vs the f64 closed form: <= 1e-4 relative to the tensor's max-abs.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import hotpath_numpy as O          # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def ops(uh_lib_path):
+    from unsuperviseddeephomographyral2018_amd import ops as _ops
+    return _ops
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# ---------------------------------------------------------------------------------------------- DLT
+def test_dlt_forward_vs_oracle(ops, dev, golden):
+    d = golden('ref_dlt_system.npz')
+    H = ops.solve_dlt(T(d['pts1'], dev), T(d['h4p'], dev)).cpu().numpy()
+    H32 = O.solve_dlt(d['pts1'], d['h4p'], np.float32)
+    H64 = O.solve_dlt_lapack64(d['pts1'], d['h4p'])
+    # same algorithm, same op order, IEEE ops -> expected bit-exact; allow 4 ulp in case of a divide difference
+    np.testing.assert_allclose(H, H32, rtol=5e-7, atol=0)
+    assert relerr(H, H64) < 1e-4
+    Hd = ops.solve_dlt(T(d['pts1'], dev), T(d['h4p'], dev), solve_f64=True).cpu().numpy()
+    np.testing.assert_allclose(Hd, H64, rtol=2e-7, atol=1e-12)
+
+
+def test_dlt_theta_fold(ops, dev, golden):
+    g = golden('chain_small.npz')
+    H, theta = ops.solve_dlt(T(g['pts1'], dev), T(g['pred_h4p'], dev), img_w=80, img_h=60)
+    np.testing.assert_allclose(H.cpu().numpy(), g['H32'], rtol=5e-7, atol=0)
+    np.testing.assert_allclose(theta.cpu().numpy(), g['theta32'], rtol=5e-7, atol=1e-9)
+
+
+def test_dlt_backward_vs_oracle(ops, dev, golden):
+    d = golden('ref_dlt_system.npz')
+    rs = np.random.RandomState(0)
+    dH = rs.randn(d['pts1'].shape[0], 3, 3).astype(np.float32)
+    for f64 in (False, True):
+        h4p = T(d['h4p'], dev).requires_grad_(True)
+        H = ops.solve_dlt(T(d['pts1'], dev), h4p, solve_f64=f64)
+        H.backward(T(dH, dev))
+        ref = O.solve_dlt_backward(d['pts1'], d['h4p'], O.solve_dlt_lapack64(d['pts1'], d['h4p']), dH)
+        # per-system scale: gradients of ill-conditioned systems are large; compare relative per row
+        err = np.abs(h4p.grad.cpu().numpy() - ref).max(1) / np.abs(ref).max(1)
+        assert err.max() < (1e-5 if f64 else 2e-3), (f64, err.max())
+        assert np.median(err) < (1e-6 if f64 else 1e-4)
+
+
+def test_dlt_backward_through_theta(ops, dev, golden):
+    g = golden('chain_small.npz')
+    h4p = T(g['pred_h4p'], dev).requires_grad_(True)
+    H, theta = ops.solve_dlt(T(g['pts1'], dev), h4p, img_w=80, img_h=60, solve_f64=True)
+    theta.backward(T(g['dtheta64'].astype(np.float32), dev))
+    assert relerr(h4p.grad.cpu().numpy(), g['dh4p64']) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- warp fwd
+def test_warp_forward_golden_bit_level(ops, dev, golden):
+    g = golden('chain_small.npz')
+    out, cond = ops.transformer(T(g['I'], dev), T(g['theta32'], dev), (60, 80))
+    out = out.cpu().numpy()
+    assert np.abs(out - g['warped32']).max() <= 1e-6
+    assert (out == g['warped32']).mean() > 0.999          # essentially bit-identical
+    # in-frame pixels vs f64 ground truth
+    xs, ys, t, xn, yn, _ = O.sample_coords(g['theta64'], 60, 80, np.float64)
+    x = (xn + 1) * 80 / 2; y = (yn + 1) * 60 / 2
+    inframe = ((x >= 0) & (x < 79) & (y >= 0) & (y < 59)).reshape(-1, 60, 80)
+    # theta32 differs from theta64 by the f32 LU; compare on a theta-identical f64 evaluation instead
+    w64, c64 = O.transformer(g['I'], g['theta32'].astype(np.float64), (60, 80), np.float64)
+    assert np.abs(out - w64)[inframe].max() < 1e-4
+    assert float(cond) == float(c64)
+
+
+def test_warp_forward_reference_test_homography(ops, dev, golden):
+    """The reference's own self-test H (numpy_spatial_transformer.py:157) on its numpy transformer's
+    output (gray image => C=1 path)."""
+    g = golden('ref_numpy_transformer.npz')
+    img = g['img'].astype(np.float32)[None, :, :, None]
+    for i in range(g['thetas'].shape[0]):
+        th = g['thetas'][i].astype(np.float32)[None]
+        out, _ = ops.transformer(T(img, dev), T(th, dev), (48, 64))
+        ref32, _ = O.transformer(img, th, (48, 64), np.float32)
+        assert np.abs(out.cpu().numpy() - ref32).max() <= 1e-4        # 0..255 range: 1e-4 abs ~ 1 ulp
+        err = np.abs(out.cpu().numpy()[0, :, :, 0] - g['outs'][i])
+        assert np.percentile(err, 99) < 5e-3
+
+
+@pytest.mark.parametrize('C', [1, 2, 3, 4])
+@pytest.mark.parametrize('shape', [(1, 37, 53, 37, 53), (3, 20, 30, 41, 70), (2, 64, 64, 16, 200)])
+def test_warp_forward_shapes_channels(ops, dev, C, shape):
+    """Ragged sizes (not multiples of the 64x16 tile), out_size != in size, every channel count."""
+    B, H, W, oh, ow = shape
+    rs = np.random.RandomState(C * 100 + H)
+    U = rs.randn(B, H, W, C).astype(np.float32)
+    theta = (np.tile(np.eye(3), (B, 1, 1)) + 0.15 * rs.randn(B, 3, 3)).astype(np.float32)
+    out, cond = ops.transformer(T(U, dev), T(theta, dev), (oh, ow))
+    ref, c = O.transformer(U, theta, (oh, ow), np.float32)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-6
+    assert float(cond) == float(c)
+
+
+def test_warp_forward_degenerate_and_far_field(ops, dev):
+    """t -> 0 lines, |x| beyond int32, NaN-free eps-guard: identical to the x86 cast semantics."""
+    rs = np.random.RandomState(3)
+    U = rs.randn(4, 24, 32, 3).astype(np.float32)
+    theta = np.array([
+        [[1, 0, 0], [0, 1, 0], [1.0, 0, 1.0 - 2e-7]],        # t crosses ~0 at the left edge
+        [[1, 0, 0], [0, 1, 0], [0.0, 0, 0.0]],               # t == 0 everywhere -> eps-guard
+        [[1e6, 0, 0], [0, 1e6, 0], [0, 0, 1e-4]],            # coordinates ~1e10 px
+        [[1, 0, 0], [0, 1, 0], [0.9, 0.9, 0.05]],            # strong perspective, sign change of t
+    ], np.float32)
+    out, cond = ops.transformer(T(U, dev), T(theta, dev), (24, 32))
+    ref, c = O.transformer(U, theta, (24, 32), np.float32)
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all() == np.isfinite(ref).all()
+    m = np.isfinite(ref)
+    # far-field weights reach 1e10: compare relative to the magnitude the op order produces
+    assert np.abs(o[m] - ref[m]).max() <= 1e-6 * max(1.0, np.abs(ref[m]).max())
+    assert float(cond) == float(c)
+
+
+def test_warp_forward_identity_sampling_law(ops, dev):
+    """Identity theta samples at x = j*W/(W-1): last row/column land exactly on W / H -> 0."""
+    U = np.random.RandomState(0).rand(1, 16, 20, 1).astype(np.float32) + 1
+    th = np.eye(3, dtype=np.float32)[None]
+    out = ops.transformer(T(U, dev), T(th, dev), (16, 20))[0].cpu().numpy()
+    ref = O.transformer(U, th, (16, 20), np.float32)[0]
+    assert np.array_equal(out, ref)
+    assert out[0, 0, 0, 0] == U[0, 0, 0, 0]
+
+
+# ---------------------------------------------------------------------------------------------- warp bwd
+def test_warp_backward_dtheta_vs_oracle(ops, dev, golden):
+    g = golden('chain_small.npz')
+    theta = T(g['theta32'], dev).requires_grad_(True)
+    out, _ = ops.transformer(T(g['I'], dev), theta, (60, 80))
+    out.backward(T(g['dOut'], dev))
+    ref = O.transformer_backward(g['I'], g['theta32'].astype(np.float64), g['dOut'], (60, 80), np.float64)
+    got = theta.grad.cpu().numpy().reshape(-1, 3, 3)
+    for k in range(got.shape[0]):
+        assert relerr(got[k], ref[k]) < 1e-4, k
+
+
+def test_warp_backward_dU_vs_oracle(ops, dev):
+    rs = np.random.RandomState(9)
+    B, H, W, C = 2, 20, 28, 3
+    U = rs.randn(B, H, W, C).astype(np.float32)
+    theta = (np.tile(np.eye(3), (B, 1, 1)) + 0.05 * rs.randn(B, 3, 3)).astype(np.float32)
+    g = rs.randn(B, H, W, C).astype(np.float32)
+    Ut = T(U, dev).requires_grad_(True); tt = T(theta, dev).requires_grad_(True)
+    out, _ = ops.transformer(Ut, tt, (H, W))
+    out.backward(T(g, dev))
+    dth, dU = O.transformer_backward(U, theta.astype(np.float64), g, (H, W), np.float64, want_dU=True)
+    assert relerr(tt.grad.cpu().numpy().reshape(-1, 3, 3), dth) < 1e-4
+    assert np.abs(Ut.grad.cpu().numpy() - dU).max() < 1e-4
+
+
+def test_warp_backward_deterministic(ops, dev):
+    rs = np.random.RandomState(2)
+    U = T(rs.randn(8, 60, 80, 3).astype(np.float32), dev)
+    th = T((np.tile(np.eye(3), (8, 1, 1)) + 0.1 * rs.randn(8, 3, 3)).astype(np.float32), dev)
+    g = T(rs.randn(8, 60, 80, 3).astype(np.float32), dev)
+    res = []
+    for _ in range(3):
+        t = th.clone().requires_grad_(True)
+        ops.transformer(U, t, (60, 80))[0].backward(g)
+        res.append(t.grad.clone())
+    assert torch.equal(res[0], res[1]) and torch.equal(res[1], res[2])
+
+
+# ---------------------------------------------------------------------------------------------- glue + loss
+def test_gray_patch_and_l1(ops, dev, golden):
+    g = golden('chain_small.npz')
+    w = T(g['warped32'], dev).requires_grad_(True)
+    idx = T(g['patch_indices'], dev)
+    pred = ops.gray_patch_gather(w, idx, 32)
+    assert np.array_equal(pred.detach().cpu().numpy(), g['pred32'])
+    loss = ops.l1_loss(pred, T(g['I2'], dev))
+    assert abs(float(loss) - float(g['loss32'])) < 1e-6
+    assert abs(float(loss) - float(g['loss64'])) < 1e-4
+    loss.backward()
+    # d loss / d warped = scatter(sign/(n*C))
+    diff = g['pred32'].reshape(6, -1) - g['I2'].reshape(6, -1)
+    ref = np.zeros((6, 60 * 80), np.float64)
+    for k in range(6):
+        np.add.at(ref[k], g['patch_indices'][k], np.sign(diff[k]) / diff.size / 3)
+    ref = np.repeat(ref.reshape(6, 60, 80, 1), 3, 3)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), ref, rtol=1e-6, atol=1e-12)
+
+
+def test_gray_patch_duplicate_indices(ops, dev):
+    """patch_indices with collisions: backward must accumulate (gather grad = scatter-ADD)."""
+    w = torch.randn(1, 4, 4, 3, device=dev, requires_grad=True)
+    idx = torch.tensor([[5, 5, 5, 7]], dtype=torch.int32, device=dev)
+    p = ops.gray_patch_gather(w, idx, 2)
+    p.backward(torch.ones_like(p))
+    gr = w.grad.reshape(16, 3).cpu().numpy()
+    np.testing.assert_allclose(gr[5], 1.0, rtol=1e-6)
+    np.testing.assert_allclose(gr[7], 1 / 3, rtol=1e-6)
+    assert np.count_nonzero(gr) == 6
+
+
+# ---------------------------------------------------------------------------------------------- chain
+def chain_unfused(ops, I, I2, pts1, h4p, idx, P, W, H, f64=False):
+    Hm, theta = ops.solve_dlt(pts1, h4p, img_w=W, img_h=H, solve_f64=f64)
+    warped, _ = ops.transformer(I, theta, (H, W))
+    pred = ops.gray_patch_gather(warped, idx, P)
+    return ops.l1_loss(pred, I2), pred, warped, theta
+
+
+def chain_fused(ops, I, I2, pts1, h4p, idx, P, W, H, f64=False):
+    Hm, theta = ops.solve_dlt(pts1, h4p, img_w=W, img_h=H, solve_f64=f64)
+    loss, pred = ops.warp_patch_l1(I, theta, I2, idx, P)
+    return loss, pred, None, theta
+
+
+@pytest.mark.parametrize('chain', [chain_unfused, chain_fused])
+def test_full_chain_vs_golden(ops, dev, golden, chain):
+    g = golden('chain_small.npz')
+    h4p = T(g['pred_h4p'], dev).requires_grad_(True)
+    loss, pred, warped, theta = chain(ops, T(g['I'], dev), T(g['I2'], dev), T(g['pts1'], dev), h4p,
+                                      T(g['patch_indices'], dev), 32, 80, 60)
+    assert abs(float(loss) - float(g['loss32'])) < 1e-6
+    assert abs(float(loss) - float(g['loss64'])) < 1e-4           # north_star: L1 within 1e-4
+    assert np.abs(pred.detach().cpu().numpy() - g['pred32']).max() <= 1e-6
+    loss.backward()
+    got = h4p.grad.cpu().numpy()
+    # f32 LU conditioning limits the per-pair agreement; the f64-solve variant is checked tighter below
+    assert relerr(got, g['dh4p64']) < 5e-3
+
+
+@pytest.mark.parametrize('chain', [chain_unfused, chain_fused])
+def test_full_chain_f64_solve_gradient(ops, dev, golden, chain):
+    g = golden('chain_small.npz')
+    h4p = T(g['pred_h4p'], dev).requires_grad_(True)
+    loss, pred, warped, theta = chain(ops, T(g['I'], dev), T(g['I2'], dev), T(g['pts1'], dev), h4p,
+                                      T(g['patch_indices'], dev), 32, 80, 60, f64=True)
+    np.testing.assert_allclose(theta.detach().cpu().numpy(), g['theta64'], rtol=1e-5, atol=1e-7)
+    assert abs(float(loss) - float(g['loss64'])) < 1e-5
+    loss.backward()
+    assert relerr(h4p.grad.cpu().numpy(), g['dh4p64']) < 2e-3
+
+
+def test_fused_equals_unfused_bitwise_and_grad(ops, dev):
+    d = O.synthetic_batch(5, 4, H=120, W=160, P=64, rho=20)
+    I, I2, pts1, idx = (T(d[k], dev) for k in ('I', 'I2', 'pts1', 'patch_indices'))
+    ha = T(d['pred_h4p'], dev).requires_grad_(True)
+    hb = T(d['pred_h4p'], dev).requires_grad_(True)
+    la, pa, _, _ = chain_unfused(ops, I, I2, pts1, ha, idx, 64, 160, 120)
+    lb, pb, _, _ = chain_fused(ops, I, I2, pts1, hb, idx, 64, 160, 120)
+    assert torch.equal(pa, pb)                       # same make_sample/blend, same channel-sum order
+    assert abs(float(la) - float(lb)) < 1e-7
+    la.backward(); lb.backward()
+    assert relerr(hb.grad.cpu().numpy(), ha.grad.cpu().numpy()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- full size
+def test_full_size_properties(ops, dev):
+    """BASELINE.json config sizes (B=64, 240x320, P=128): properties that need no full-size oracle,
+    plus the oracle on a 2-image subset."""
+    B, H, W, P = 64, 240, 320, 128
+    d = O.synthetic_batch(1, 2, H=H, W=W, P=P, rho=45)
+    gen = torch.Generator(device='cpu').manual_seed(0)
+    U = torch.randn(B, H, W, 3, generator=gen).to(dev)
+    U[:2] = T(d['I'], dev)
+    x0 = torch.randint(45, 148, (B,), generator=gen); y0 = torch.randint(45, 68, (B,), generator=gen)
+    pts1 = torch.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).float()
+    pts1[:2] = torch.from_numpy(d['pts1'])
+    h4p = torch.randint(-45, 46, (B, 8), generator=gen).float() + torch.randn(B, 8, generator=gen)
+    h4p[:2] = torch.from_numpy(d['pred_h4p'])
+    Hm, theta = ops.solve_dlt(pts1.to(dev), h4p.to(dev), img_w=W, img_h=H)
+    out, cond = ops.transformer(U, theta, (H, W))
+    # (1) oracle on the first two images, every pixel, identical theta
+    th_np = theta[:2].cpu().numpy()
+    ref, _ = O.transformer(d['I'], th_np, (H, W), np.float32)
+    assert np.abs(out[:2].cpu().numpy() - ref).max() <= 1e-6
+    w64, _ = O.transformer(d['I'], th_np.astype(np.float64), (H, W), np.float64)
+    xs, ys, t, xn, yn, _ = O.sample_coords(th_np.astype(np.float64), H, W, np.float64)
+    x = (xn + 1) * W / 2; y = (yn + 1) * H / 2
+    inframe = ((x >= 0) & (x < W - 1) & (y >= 0) & (y < H - 1)).reshape(2, H, W)
+    assert np.abs(out[:2].cpu().numpy() - w64)[inframe].max() < 1e-4          # north_star tolerance
+    # (2) linearity in U (bilinear sampling is linear): warp(a U1 + U2) = a warp(U1) + warp(U2)
+    U2 = torch.randn_like(U)
+    lhs = ops.transformer(2.0 * U + U2, theta, (H, W))[0]
+    rhs = 2.0 * out + ops.transformer(U2, theta, (H, W))[0]
+    assert np.abs((lhs - rhs)[:2].cpu().numpy())[inframe].max() <= 1e-4
+    assert float((lhs - rhs).abs().median()) < 1e-5
+    # (3) constant image: in-frame weights sum to 1 -> output is that constant wherever all four
+    #     corners are distinct, 0 where the clip collapsed a pair
+    ones = torch.full_like(U, 3.0)
+    oc = ops.transformer(ones, theta, (H, W))[0][:2].cpu().numpy()
+    assert np.abs(oc[inframe] - 3.0).max() < 1e-3
+    # (4) determinism, forward and backward
+    out2, _ = ops.transformer(U, theta, (H, W))
+    assert torch.equal(out, out2)
+    assert float(cond) == B * H * W            # no |t| <= 1e-7 sample (measure zero)
+    g = torch.randn_like(out)
+    t1 = theta.detach().clone().requires_grad_(True); t2 = theta.detach().clone().requires_grad_(True)
+    ops.transformer(U, t1, (H, W))[0].backward(g); ops.transformer(U, t2, (H, W))[0].backward(g)
+    assert torch.equal(t1.grad, t2.grad)
+    # (5) dTheta of the first two images vs the f64 closed form (full-frame random dOut)
+    refd = O.transformer_backward(d['I'], th_np.astype(np.float64), g[:2].cpu().numpy(), (H, W), np.float64)
+    got = t1.grad[:2].cpu().numpy().reshape(2, 3, 3)
+    for k in range(2):
+        assert relerr(got[k], refd[k]) < 1e-4
+
+
+def test_full_size_fused_patch_vs_oracle(ops, dev):
+    B, H, W, P = 8, 240, 320, 128
+    d = O.synthetic_batch(2, B, H=H, W=W, P=P, rho=45)
+    bw = O.photometric_chain_backward(d['I'], d['I2'], d['pts1'], d['pred_h4p'], d['patch_indices'], P)
+    for chain in (chain_unfused, chain_fused):
+        h4p = T(d['pred_h4p'], dev).requires_grad_(True)
+        loss, pred, _, theta = chain(ops, T(d['I'], dev), T(d['I2'], dev), T(d['pts1'], dev), h4p,
+                                     T(d['patch_indices'], dev), P, W, H, f64=True)
+        assert abs(float(loss) - bw['l1_loss']) < 1e-4
+        assert np.abs(pred.detach().cpu().numpy() - bw['pred_I2']).max() < 1e-3
+        loss.backward()
+        assert relerr(h4p.grad.cpu().numpy(), bw['dh4p']) < 5e-3, chain.__name__
+
+
+def test_native_library_is_loaded(ops, dev):
+    """The process must have the in-tree .so mapped (no silent fallback)."""
+    ops.solve_dlt(torch.zeros(1, 8, device=dev) + torch.tensor([0., 0, 1, 0, 1, 1, 0, 1], device=dev),
+                  torch.zeros(1, 8, device=dev))
+    maps = open('/proc/self/maps').read()
+    assert 'libuh_hotpath.so' in maps

@@ -1,0 +1,81 @@
+"""ctypes binding of include/uh_hotpath.h.  There is NO fallback: if the library is missing or a
+symbol is absent, importing/using the ops raises -- the product path never computes on CPU."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libuh_hotpath.so')
+
+UH_ABI_VERSION = 1
+UH_DLT_SOLVE_F32 = 0
+UH_DLT_SOLVE_F64 = 1
+KERNEL_COUNT = 11
+
+_p = C.c_void_p
+_i = C.c_int
+_u = C.c_uint
+_z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/uh_hotpath.h one to one
+SIGNATURES = {
+    'uh_abi_version': (_i, []),
+    'uh_error_string': (C.c_char_p, [_i]),
+    'uh_dlt_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _u, _p]),
+    'uh_dlt_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _u, _p]),
+    'uh_warp_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'uh_warp_backward_workspace_bytes': (_z, [_i, _i, _i, _i, _i, _i]),
+    'uh_warp_backward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),
+    'uh_gray_patch_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'uh_gray_patch_backward': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'uh_l1_loss_workspace_bytes': (_z, [_z]),
+    'uh_l1_loss_forward': (_i, [_p, _p, _p, _p, _z, _z, _p]),
+    'uh_l1_loss_backward': (_i, [_p, _p, _p, _p, _z, _p]),
+    'uh_warp_patch_l1_workspace_bytes': (_z, [_i, _i]),
+    'uh_warp_patch_l1_fwdbwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
+    'uh_profile_enable': (_i, [_i]),
+    'uh_profile_read': (_i, [_p, _p]),
+    'uh_kernel_name': (C.c_char_p, [_i]),
+}
+
+_lib = None
+
+
+class UHError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libuh_hotpath.so (once) and type every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UHError('%s not found -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                      '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.uh_abi_version() != UH_ABI_VERSION:
+        raise UHError('ABI version mismatch: library %d, binding %d' % (lib.uh_abi_version(), UH_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise UHError('%s failed: %s (code %d)' % (what, load().uh_error_string(code).decode(), code))
+
+
+def profile_enable(on):
+    return load().uh_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """-> {kernel_name: (total_ms, launches)}"""
+    lib = load()
+    ms = (C.c_double * KERNEL_COUNT)()
+    n = (C.c_longlong * KERNEL_COUNT)()
+    check(lib.uh_profile_read(ms, n), 'uh_profile_read')
+    return {lib.uh_kernel_name(k).decode(): (ms[k], n[k]) for k in range(KERNEL_COUNT)}

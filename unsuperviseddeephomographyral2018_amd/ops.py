@@ -1,0 +1,269 @@
+"""Host-side operators over the C ABI (include/uh_hotpath.h).
+
+torch is used for device memory, streams and autograd bookkeeping only: every number is produced by
+the HIP kernels in csrc/.  All tensors must live on a HIP device ("cuda" in torch-ROCm); passing CPU
+tensors raises -- there is no CPU fallback.
+
+Mirrors, by name and argument meaning:
+  transformer(U, theta, out_size)       /root/reference/code/utils/tf_spatial_transformer.py:18
+  solve_dlt(pts1, h4p)                  /root/reference/code/homography_model.py:169-250
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.UHError('%s must be a tensor on the HIP device (got %s); the hot path has no CPU fallback'
+                           % (name, getattr(t, 'device', type(t))))
+    if t.dtype != torch.float32:
+        raise _lib.UHError('%s must be float32 (got %s)' % (name, t.dtype))
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _host9(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(9))
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def m_and_minv(img_w, img_h):
+    """The reference's constants (homography_model.py:63-69): M in f32, M^-1 by np.linalg.inv."""
+    M = np.array([[img_w / 2.0, 0., img_w / 2.0],
+                  [0., img_h / 2.0, img_h / 2.0],
+                  [0., 0., 1.]]).astype(np.float32)
+    return M, np.linalg.inv(M)
+
+
+# ------------------------------------------------------------------------------------------------
+class _DLTSolve(torch.autograd.Function):
+    """pts1, h4p -> (H [B,3,3], theta [B,3,3] or None).  Gradient flows to h4p only (pts1 is data)."""
+
+    @staticmethod
+    def forward(ctx, pts1, h4p, M, Minv, flags):
+        lib = _lib.load()
+        pts1 = _f32(pts1, 'pts1').reshape(-1, 8)
+        h4p = _f32(h4p, 'h4p').reshape(-1, 8)
+        B = pts1.shape[0]
+        if h4p.shape[0] != B:
+            raise _lib.UHError('pts1 and h4p batch mismatch')
+        H = torch.empty((B, 3, 3), dtype=torch.float32, device=pts1.device)
+        theta = torch.empty_like(H) if M is not None else None
+        Mh = Mih = None
+        if M is not None:
+            ctx.M_keep, Mh = _host9(M)
+            ctx.Mi_keep, Mih = _host9(Minv)
+        _lib.check(lib.uh_dlt_forward(_ptr(pts1), _ptr(h4p), _ptr(H), _ptr(theta), Mh, Mih, B, flags, _stream()),
+                   'uh_dlt_forward')
+        ctx.save_for_backward(pts1, h4p, H)
+        ctx.set_materialize_grads(False)       # an unused output arrives as None, not as zeros
+        ctx.flags = flags
+        ctx.has_theta = M is not None
+        if theta is None:
+            return H
+        return H, theta
+
+    @staticmethod
+    def backward(ctx, dH, dtheta=None):
+        lib = _lib.load()
+        pts1, h4p, H = ctx.saved_tensors
+        B = pts1.shape[0]
+        dh4p = torch.empty((B, 8), dtype=torch.float32, device=pts1.device)
+
+        def run(gH, gT):
+            Mh = Mih = None
+            if gT is not None:      # ctx.*_keep own the host buffers for the duration of the call
+                Mh = ctx.M_keep.ctypes.data_as(C.c_void_p)
+                Mih = ctx.Mi_keep.ctypes.data_as(C.c_void_p)
+            _lib.check(lib.uh_dlt_backward(_ptr(pts1), _ptr(h4p), _ptr(H), _ptr(gH), _ptr(gT), Mh, Mih,
+                                           _ptr(dh4p), B, ctx.flags, _stream()), 'uh_dlt_backward')
+
+        if dH is None and dtheta is None:
+            return None, torch.zeros_like(dh4p), None, None, None
+        if dH is None:
+            run(None, _f32(dtheta, 'dtheta'))
+        elif dtheta is not None:
+            # both outputs used downstream: dH_total = dH + Minv^T dtheta M^T  (rare; monitoring code)
+            Mt = torch.from_numpy(ctx.M_keep.reshape(3, 3)).to(dH.device)
+            Mit = torch.from_numpy(ctx.Mi_keep.reshape(3, 3)).to(dH.device)
+            run((dH + Mit.t() @ dtheta @ Mt.t()).contiguous(), None)
+        else:
+            run(_f32(dH, 'dH'), None)
+        return None, dh4p, None, None, None
+
+
+def solve_dlt(pts1, h4p, img_w=None, img_h=None, solve_f64=False):
+    """Tensor-DLT.  Returns H [B,3,3]; with img_w/img_h also theta = M^-1 H M (transform() :254)."""
+    flags = _lib.UH_DLT_SOLVE_F64 if solve_f64 else _lib.UH_DLT_SOLVE_F32
+    if img_w is None:
+        return _DLTSolve.apply(pts1, h4p, None, None, flags)
+    M, Minv = m_and_minv(img_w, img_h)
+    return _DLTSolve.apply(pts1, h4p, M, Minv, flags)
+
+
+# ------------------------------------------------------------------------------------------------
+class _ProjectiveWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, theta, out_h, out_w, want_condition):
+        lib = _lib.load()
+        U = _f32(U, 'U')
+        if U.dim() != 4:
+            raise _lib.UHError('U must be [B,H,W,C]')
+        B, H, W, Cc = U.shape
+        theta = _f32(theta, 'theta').reshape(-1, 9)
+        if theta.shape[0] != B:
+            raise _lib.UHError('theta must be [B,3,3] / [B,9]')
+        out = torch.empty((B, out_h, out_w, Cc), dtype=torch.float32, device=U.device)
+        cond = torch.empty((1,), dtype=torch.float32, device=U.device) if want_condition else None
+        _lib.check(lib.uh_warp_forward(_ptr(U), _ptr(theta), _ptr(out), _ptr(cond), B, H, W, Cc, out_h, out_w,
+                                       _stream()), 'uh_warp_forward')
+        ctx.save_for_backward(U, theta)
+        ctx.dims = (B, H, W, Cc, out_h, out_w)
+        ctx.theta_shape = None
+        if want_condition:
+            ctx.mark_non_differentiable(cond)
+            return out, cond
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut, dcond=None):
+        lib = _lib.load()
+        U, theta = ctx.saved_tensors
+        B, H, W, Cc, oh, ow = ctx.dims
+        dOut = _f32(dOut, 'dOut')
+        dTheta = torch.empty((B, 9), dtype=torch.float32, device=U.device)
+        dU = torch.empty_like(U) if ctx.needs_input_grad[0] else None
+        nbytes = lib.uh_warp_backward_workspace_bytes(B, H, W, Cc, oh, ow)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_warp_backward(_ptr(U), _ptr(theta), _ptr(dOut), _ptr(dTheta), _ptr(dU), _ptr(ws), nbytes,
+                                        B, H, W, Cc, oh, ow, _stream()), 'uh_warp_backward')
+        return dU, dTheta, None, None, None
+
+
+def transformer(U, theta, out_size, name='SpatialTransformer', with_condition=True, **kwargs):
+    """Spatial Transformer Layer -- same signature and return as the reference's
+    transformer(U, theta, out_size) -> (output, condition)  (tf_spatial_transformer.py:18,249-251).
+    theta may be [B,3,3], [B,9] ... anything reshapable to (-1,3,3) (:190)."""
+    th_shape = theta.shape
+    res = _ProjectiveWarp.apply(U, theta.reshape(-1, 9), int(out_size[0]), int(out_size[1]), with_condition)
+    del th_shape
+    if with_condition:
+        return res[0], res[1][0]
+    return res, None
+
+
+# ------------------------------------------------------------------------------------------------
+class _GrayPatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, warped, patch_idx, patch_size):
+        lib = _lib.load()
+        warped = _f32(warped, 'warped')
+        B, H, W, Cc = warped.shape
+        if patch_idx.dtype != torch.int32 or not patch_idx.is_cuda:
+            raise _lib.UHError('patch_indices must be an int32 tensor on the HIP device')
+        idx = patch_idx.contiguous().reshape(B, -1)
+        PP = idx.shape[1]
+        pred = torch.empty((B, PP), dtype=torch.float32, device=warped.device)
+        _lib.check(lib.uh_gray_patch_forward(_ptr(warped), _ptr(idx), _ptr(pred), B, H, W, Cc, PP, _stream()),
+                   'uh_gray_patch_forward')
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, H, W, Cc, PP)
+        return pred.reshape(B, patch_size, patch_size, 1)
+
+    @staticmethod
+    def backward(ctx, dPred):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        B, H, W, Cc, PP = ctx.dims
+        dPred = _f32(dPred, 'dPred')
+        dW = torch.empty((B, H, W, Cc), dtype=torch.float32, device=dPred.device)
+        _lib.check(lib.uh_gray_patch_backward(_ptr(dPred), _ptr(idx), _ptr(dW), B, H, W, Cc, PP, _stream()),
+                   'uh_gray_patch_backward')
+        return dW, None, None
+
+
+def gray_patch_gather(warped, patch_indices, patch_size):
+    """reduce_mean(axis=3) + flat gather (homography_model.py:263-269) -> [B,P,P,1]."""
+    return _GrayPatch.apply(warped, patch_indices, patch_size)
+
+
+class _L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        lib = _lib.load()
+        pred = _f32(pred, 'pred'); target = _f32(target, 'target')
+        n = pred.numel()
+        if target.numel() != n:
+            raise _lib.UHError('pred/target size mismatch')
+        loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+        nbytes = lib.uh_l1_loss_workspace_bytes(n)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=pred.device)
+        _lib.check(lib.uh_l1_loss_forward(_ptr(pred), _ptr(target), _ptr(loss), _ptr(ws), nbytes, n, _stream()),
+                   'uh_l1_loss_forward')
+        ctx.save_for_backward(pred, target)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dLoss):
+        lib = _lib.load()
+        pred, target = ctx.saved_tensors
+        g = _f32(dLoss.reshape(1), 'dLoss')
+        dPred = torch.empty_like(pred)
+        _lib.check(lib.uh_l1_loss_backward(_ptr(pred), _ptr(target), _ptr(g), _ptr(dPred), pred.numel(), _stream()),
+                   'uh_l1_loss_backward')
+        return dPred, None
+
+
+def l1_loss(pred, target):
+    """reduce_mean(abs(pred - target)) (homography_model.py:328)."""
+    return _L1Loss.apply(pred, target)
+
+
+# ------------------------------------------------------------------------------------------------
+class _WarpPatchL1(torch.autograd.Function):
+    """Fused patch path: (U, theta, I2, patch_idx) -> (loss, pred_I2).  The kernel produces dTheta for
+    dLoss = 1 in the same pass; backward just scales it."""
+
+    @staticmethod
+    def forward(ctx, U, theta, I2, patch_idx, patch_size):
+        lib = _lib.load()
+        U = _f32(U, 'U'); I2 = _f32(I2, 'I2')
+        B, H, W, Cc = U.shape
+        theta = _f32(theta, 'theta').reshape(-1, 9)
+        if patch_idx.dtype != torch.int32 or not patch_idx.is_cuda:
+            raise _lib.UHError('patch_indices must be an int32 tensor on the HIP device')
+        idx = patch_idx.contiguous().reshape(B, -1)
+        PP = idx.shape[1]
+        pred = torch.empty((B, PP), dtype=torch.float32, device=U.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=U.device)
+        need_grad = ctx.needs_input_grad[1]
+        dTheta = torch.empty((B, 9), dtype=torch.float32, device=U.device) if need_grad else None
+        nbytes = lib.uh_warp_patch_l1_workspace_bytes(B, PP)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_warp_patch_l1_fwdbwd(_ptr(U), _ptr(theta), _ptr(I2), _ptr(idx), _ptr(pred), _ptr(loss),
+                                               _ptr(dTheta), _ptr(ws), nbytes, B, H, W, Cc, PP, _stream()),
+                   'uh_warp_patch_l1_fwdbwd')
+        ctx.dTheta = dTheta
+        pred = pred.reshape(B, patch_size, patch_size, 1)
+        ctx.mark_non_differentiable(pred)
+        return loss[0], pred
+
+    @staticmethod
+    def backward(ctx, dLoss, dPred=None):
+        return None, (ctx.dTheta * dLoss).reshape(-1, 9), None, None, None
+
+
+def warp_patch_l1(U, theta, I2, patch_indices, patch_size):
+    """-> (l1_loss scalar, pred_I2 [B,P,P,1]); pred_I2 carries no gradient on this path."""
+    return _WarpPatchL1.apply(U, theta.reshape(-1, 9), I2, patch_indices, patch_size)
