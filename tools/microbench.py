@@ -99,11 +99,15 @@ def run(B, H, W, P, rho, iters, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--configs', default='64,240,320,128,45;128,240,320,128,45;128,480,640,128,64',
+                    help='semicolon-separated B,H,W,P,rho')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
-    print(torch.cuda.get_device_name(0), file=sys.stderr)
-    for (B, H, W, P, rho) in ((64, 240, 320, 128, 45), (128, 240, 320, 128, 45), (128, 480, 640, 128, 64)):
-        print(json.dumps(run(B, H, W, P, rho, args.iters, dev)), flush=True)
+    for cfg in args.configs.split(';'):
+        B, H, W, P, rho = (int(v) for v in cfg.split(','))
+        r = run(B, H, W, P, rho, args.iters, dev)
+        r['lib'] = os.path.basename(_lib.LIB_PATH)
+        print(json.dumps(r), flush=True)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Build A/B variants of the library (developer tool): tools/variants.sh name "-DFLAG ..." ...
+set -e
+cd "$(dirname "$0")/../unsuperviseddeephomographyral2018_amd/csrc"
+OUT=../lib/variants; mkdir -p $OUT
+while [ $# -gt 1 ]; do
+  name=$1; flags=$2; shift 2
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden $flags \
+     uh_dlt.hip uh_warp.hip uh_misc.hip uh_patch.hip -o $OUT/libuh_$name.so &
+done
+wait
+ls -la $OUT

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libuh_hotpath.so')
+# UH_LIB_PATH lets a developer A/B a differently-built copy of the SAME library (tools/); it is not a fallback.
+LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hotpath.so')
 
 UH_ABI_VERSION = 1
 UH_DLT_SOLVE_F32 = 0

@@ -68,6 +68,9 @@ __device__ __forceinline__ float blend(const Sample& s, float Ia, float Ib, floa
 // ids so that the tiles of one image (which share source rows) meet in one 4 MiB L2.  Bijective for
 // any grid size (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").  Speed only.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+#ifdef UH_NO_XCD_REMAP            // developer A/B switch only (tools/variants.sh)
+    return bid;
+#endif
     unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, slot = bid >> 3;
     unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
     return base + slot;

@@ -15,8 +15,9 @@
 
 namespace uh {
 
-constexpr int PB = 256;      // patch pixels per block
-constexpr int NACC = 10;     // 9 dTheta sums + 1 |diff| sum
+constexpr int PPT = 4;             // patch pixels per thread (amortises the block reduction)
+constexpr int PB = 256 * PPT;      // patch pixels per block
+constexpr int NACC = 10;           // 9 dTheta sums + 1 |diff| sum
 
 template <int C, bool WANT_GRAD>
 __global__ __launch_bounds__(256) void warp_patch_l1_kernel(
@@ -27,16 +28,19 @@ __global__ __launch_bounds__(256) void warp_patch_l1_kernel(
     const unsigned v = xcd_remap(blockIdx.x, nblk);
     const int b = v / blocks_per_image, chunk = v - b * blocks_per_image;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = chunk * PB + threadIdx.x;
     Theta th;
 #pragma unroll
     for (int j = 0; j < 9; ++j) th.a[j] = theta[(size_t)b * 9 + j];
     const float* __restrict__ Ub = U + (size_t)b * H * W * C;
     const float sx = lin_step(W), sy = lin_step(H);
+    const float halfW = (float)W * 0.5f, halfH = (float)H * 0.5f;
     float acc[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
-    if (i < PP) {
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int i = chunk * PB + k * 256 + threadIdx.x;
+        if (i >= PP) break;
         const size_t e = (size_t)b * PP + i;
         const int idx = patch_idx[e];
         const int row = idx / W, col = idx - row * W;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(256) void warp_patch_l1_kernel(
         const float p = gsum / (float)C;
         pred[e] = p;
         const float d = p - I2[e];
-        acc[9] = fabsf(d);
+        acc[9] += fabsf(d);
         if (WANT_GRAD) {
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
             float ex = 0.f, ey = 0.f;
@@ -65,11 +69,11 @@ __global__ __launch_bounds__(256) void warp_patch_l1_kernel(
             }
             const float g = sgn / (float)C;
             const float rt = 1.0f / s.t;
-            const float dxs = g * ex * ((float)W * 0.5f) * rt, dys = g * ey * ((float)H * 0.5f) * rt;
+            const float dxs = g * ex * halfW * rt, dys = g * ey * halfH * rt;
             const float dt = -(dxs * s.xs + dys * s.ys) * rt;
-            acc[0] = dxs * gx; acc[1] = dxs * gy; acc[2] = dxs;
-            acc[3] = dys * gx; acc[4] = dys * gy; acc[5] = dys;
-            acc[6] = dt * gx;  acc[7] = dt * gy;  acc[8] = dt;
+            acc[0] = fmaf(dxs, gx, acc[0]); acc[1] = fmaf(dxs, gy, acc[1]); acc[2] += dxs;
+            acc[3] = fmaf(dys, gx, acc[3]); acc[4] = fmaf(dys, gy, acc[4]); acc[5] += dys;
+            acc[6] = fmaf(dt,  gx, acc[6]); acc[7] = fmaf(dt,  gy, acc[7]); acc[8] += dt;
         }
     }
 #pragma unroll
@@ -84,8 +88,9 @@ __global__ __launch_bounds__(256) void warp_patch_l1_kernel(
     }
 }
 
-// One block finishes everything deterministically: wave w sums images w, w+16, ... (f64), writes their
-// dTheta; the |diff| sums meet in LDS for the scalar loss.
+// One block finishes everything deterministically.  Thread q owns one (image b, accumulator j) pair
+// and adds that image's per-block partials in f64 in fixed order (adjacent threads read adjacent
+// floats); the |diff| sums (j == 9) then meet in LDS for the scalar loss.
 __global__ __launch_bounds__(1024) void warp_patch_l1_finish_kernel(const float* __restrict__ partial,
                                                                     float* __restrict__ loss,
                                                                     float* __restrict__ dTheta, int B,
@@ -93,25 +98,16 @@ __global__ __launch_bounds__(1024) void warp_patch_l1_finish_kernel(const float*
     __shared__ double lsum[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double lacc = 0.0;
-    for (int b = wave; b < B; b += 16) {
-        double acc[NACC];
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
-        for (int t = lane; t < blocks_per_image; t += 64) {
-            const float* p = partial + ((size_t)b * blocks_per_image + t) * NACC;
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) acc[j] += (double)p[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) acc[j] = wave_sum(acc[j]);
-        if (lane == 0) {
-            if (dTheta) {
-#pragma unroll
-                for (int j = 0; j < 9; ++j) dTheta[(size_t)b * 9 + j] = (float)(acc[j] * inv_n);
-            }
-            lacc += acc[9];
-        }
+    for (int q = threadIdx.x; q < B * NACC; q += 1024) {
+        const int b = q / NACC, j = q - b * NACC;
+        const float* p = partial + (size_t)b * blocks_per_image * NACC + j;
+        double a = 0.0;
+#pragma unroll 8
+        for (int t = 0; t < blocks_per_image; ++t) a += (double)p[(size_t)t * NACC];
+        if (j < 9) { if (dTheta) dTheta[(size_t)b * 9 + j] = (float)(a * inv_n); }
+        else lacc += a;
     }
+    lacc = wave_sum(lacc);
     if (lane == 0) lsum[wave] = lacc;
     __syncthreads();
     if (threadIdx.x == 0) {

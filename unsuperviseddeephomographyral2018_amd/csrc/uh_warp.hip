@@ -194,21 +194,28 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
 }
 
 // Deterministic finish: dTheta[b][j] = sum over the image's tiles, accumulated in f64, fixed order.
-__global__ __launch_bounds__(64) void warp_backward_finish_kernel(const float* __restrict__ partial,
-                                                                  float* __restrict__ dTheta, int tiles) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    double acc[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) acc[j] = 0.0;
-    for (int t = lane; t < tiles; t += 64) {
-        const float* p = partial + ((size_t)b * tiles + t) * 9;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) acc[j] += (double)p[j];
+// One wave per image.  The image's partials are `tiles*9` contiguous floats; lane l < 63 walks them
+// with stride 63 (= 7*9), so its accumulator index j = l % 9 never changes and every load instruction
+// is coalesced and independent of the others; the 7 lanes that share a j then meet in LDS.
+__global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* __restrict__ partial,
+                                                                   float* __restrict__ dTheta, int tiles, int B) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    double a = 0.0;
+    if (b < B && lane < 63) {
+        const float* p = partial + (size_t)b * tiles * 9;
+        const int n = tiles * 9;
+#pragma unroll 4
+        for (int e = lane; e < n; e += 63) a += (double)p[e];
     }
+    red[wave][lane] = a;
+    __syncthreads();
+    if (b < B && lane < 9) {
+        double t = 0.0;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const double r = wave_sum(acc[j]);
-        if (lane == 0) dTheta[(size_t)b * 9 + j] = (float)r;
+        for (int k = 0; k < 7; ++k) t += red[wave][lane + 9 * k];
+        dTheta[(size_t)b * 9 + lane] = (float)t;
     }
 }
 
@@ -309,7 +316,7 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
     {
         ProfScope prof(UH_K_WARP_BWD_FIN, s);
         const TileGeom g = tile_geom(oh, ow, UH_WARP_ROWS);
-        hipLaunchKernelGGL(warp_backward_finish_kernel, dim3(B), dim3(64), 0, s, partial, dTheta, g.tiles);
+        hipLaunchKernelGGL(warp_backward_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, s, partial, dTheta, g.tiles, B);
     }
     return (int)hipGetLastError();
 }

@@ -1,0 +1,122 @@
+"""Data parallelism: one process per GPU, gradient averaging over RCCL (xGMI).
+
+Replaces the reference's in-graph tower loop + get_average_grads
+(/root/reference/code/homography_CNN_synthetic.py:199-207,229-278, utils/utils.py:380-403): there the
+batch is tf.split over --num_gpus towers in ONE process and per-variable tower gradients are
+expand_dims -> concat -> reduce_mean on the default device.  Here every rank owns a contiguous shard
+(B_local = B / world), computes the mean loss over ITS shard (so h_loss stays an RMSE per tower) and
+the 34.19 M f32 gradients are averaged with two flat all-reduces:
+
+    bucket 0 = fc2 + fc1   (134.3 MB; produced FIRST in backward  -> its all-reduce runs under the whole
+                            conv backward)
+    bucket 1 = conv1..8    (2.6 MB; produced last)
+
+Gradients are persistent views into the flat bucket buffers, so there is no pack/unpack copy; the
+all-reduce of a bucket is issued (async) by the post-accumulate hook of the LAST parameter of the bucket
+to receive its gradient.  The hot path itself (DLT / warp / loss) has no parameters => no collective.
+xGMI is point-to-point (7 links x ~153 GB/s): RCCL's direct reduce-scatter + all-gather moves 1/8 of
+a bucket per link per phase (~0.11 ms for bucket 0) -- hidden under >= 3 ms of conv backward.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank).  World size 1 => no process group at all."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'     # "nccl" IS RCCL on ROCm
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard(tensor, rank, world):
+    """Contiguous batch shard of this rank -- tf.split(x, num_gpus, 0)[rank]."""
+    B = tensor.shape[0]
+    if B % world:
+        raise ValueError('batch %d not divisible by world size %d' % (B, world))
+    n = B // world
+    return tensor[rank * n:(rank + 1) * n]
+
+
+class GradAverager(object):
+    """Bucketed, overlapped gradient mean (== utils.get_average_grads across towers)."""
+
+    def __init__(self, module, world=None, first_bucket=('fc2', 'fc1')):
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        b0 = [(n, p) for n, p in params if n.split('.')[0] in first_bucket]
+        b1 = [(n, p) for n, p in params if n.split('.')[0] not in first_bucket]
+        self.buckets = []
+        self._handles = []
+        self._hooks = []
+        for plist in (b0, b1):
+            if not plist:
+                continue
+            total = sum(p.numel() for _, p in plist)
+            flat = torch.zeros(total, dtype=plist[0][1].dtype, device=plist[0][1].device)
+            off = 0
+            for _, p in plist:
+                p.grad = flat[off:off + p.numel()].view_as(p)        # persistent view: no pack/unpack
+                off += p.numel()
+            bucket = {'flat': flat, 'params': [p for _, p in plist], 'pending': 0}
+            self.buckets.append(bucket)
+            for _, p in plist:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bucket)))
+        self.reset()
+
+    def _make_hook(self, bucket):
+        def hook(param):
+            bucket['pending'] -= 1
+            if bucket['pending'] == 0 and self.world > 1:
+                self._handles.append(dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, async_op=True))
+        return hook
+
+    def reset(self):
+        """Call before each backward: zero the flat buffers (in place, views stay valid)."""
+        self._handles = []
+        for b in self.buckets:
+            b['flat'].zero_()
+            b['pending'] = len(b['params'])
+            for p in b['params']:            # an optimizer may have detached .grad (set_to_none)
+                if p.grad is None or p.grad.data_ptr() < b['flat'].data_ptr() or \
+                        p.grad.data_ptr() >= b['flat'].data_ptr() + b['flat'].numel() * b['flat'].element_size():
+                    raise RuntimeError('GradAverager: a .grad no longer aliases its bucket; use '
+                                       'optimizer.zero_grad(set_to_none=False) or GradAverager.reset() only')
+
+    def finish(self):
+        """Call after backward, before optimizer.step(): wait for the all-reduces and divide by world."""
+        if self.world > 1:
+            for b in self.buckets:
+                if b['pending'] != 0:          # a parameter received no gradient: reduce it now
+                    self._handles.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True))
+            for h in self._handles:
+                h.wait()
+            for b in self.buckets:
+                b['flat'].div_(self.world)
+        self._handles = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def all_reduce_mean_scalars(values, world):
+    """Mean over ranks of a few logging scalars (total_*_loss = reduce_mean over towers, :279-284)."""
+    if world == 1:
+        return values
+    t = torch.stack([v.detach().float().reshape(()) for v in values])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = t / world
+    return [t[i] for i in range(len(values))]

@@ -1,0 +1,244 @@
+"""Trainer / evaluator -- mirror of /root/reference/code/homography_CNN_synthetic.py.
+
+Keeps the reference's CLI flags (:49-85), optimizer and learning-rate law (:161-183: Adam,
+exponential_decay(lr, step, int(decay_steps), 0.96, staircase) with
+decay_steps = ln(.96)*150000/ln(min_lr/lr)), the per-tower model construction (:229-257), gradient
+averaging (:277-278 -> dist.GradAverager over RCCL) and the test-mode statistics (:391-580), as an
+eager one-process-per-GPU program.  The TF queue-runner input pipeline (dataloader.py) is out of scope
+(SURVEY section 8): pairs come from synthetic.make_batch with the same sampling law, resident in HBM.
+
+    python -m unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic --mode train --batch_size 64 \
+        --loss_type l1_loss --num_total_steps 200
+    torchrun --nproc-per-node 8 -m unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic --batch_size 512
+"""
+import argparse
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dist as uh_dist
+from . import synthetic
+from .homography_model import HomographyModel, VGGRegressor, homography_model_params
+
+# Size of synthetic image and the pertubation range (RH0)      (:14-17)
+HEIGHT = 240
+WIDTH = 320
+RHO = 45
+PATCH_SIZE = 128
+AUGMENT_LIST = ['normalize']
+
+
+def str2bool(s):
+    return s.lower() == 'true'
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--mode', type=str, default='train', help='Train or test', choices=['train', 'test'])
+    p.add_argument('--loss_type', type=str, default='l1_loss', help='Loss type',
+                   choices=['h_loss', 'rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss'])
+    p.add_argument('--use_batch_norm', type=str2bool, default='False', help='Use batch_norm?')
+    p.add_argument('--leftright_consistent_weight', type=float, default=0)
+    p.add_argument('--augment_list', nargs='+', default=AUGMENT_LIST, help='List of augmentations')
+    p.add_argument('--do_augment', type=float, default=0.5)
+    p.add_argument('--num_gpus', type=int, default=None,
+                   help='Number of splits.  Here = WORLD_SIZE (one process per GPU); kept for CLI compatibility')
+    p.add_argument('--log_dir', type=str, default='../logs/')
+    p.add_argument('--results_dir', type=str, default='../results/synthetic/report/')
+    p.add_argument('--model_dir', type=str, default='../models/synthetic_models')
+    p.add_argument('--model_name', type=str, default='model.ckpt')
+    p.add_argument('--img_w', type=int, default=WIDTH)
+    p.add_argument('--img_h', type=int, default=HEIGHT)
+    p.add_argument('--patch_size', type=int, default=PATCH_SIZE)
+    p.add_argument('--batch_size', type=int, default=128)
+    p.add_argument('--max_epoches', type=int, default=150)
+    p.add_argument('--lr', type=float, default=1e-4, help='Max learning rate')
+    p.add_argument('--min_lr', type=float, default=.9e-4, help='Min learning rate')
+    p.add_argument('--resume', type=str2bool, default='False')
+    p.add_argument('--retrain', type=str2bool, default='False')
+    # --- additions (not in the reference) ---
+    p.add_argument('--rho', type=int, default=RHO)
+    p.add_argument('--num_total_steps', type=int, default=150000, help='the reference hard-codes 150000 (:159)')
+    p.add_argument('--num_test_data', type=int, default=1024, help='synthetic stand-in for the test file list')
+    p.add_argument('--fused_patch', type=str2bool, default='False',
+                   help='l1_loss only: fused patch kernel instead of the full-frame warp')
+    p.add_argument('--solve_f64', type=str2bool, default='False', help='carry the 8x8 DLT solve in f64')
+    p.add_argument('--fresh_data_every', type=int, default=1, help='draw a new synthetic batch every N steps')
+    p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--log_every', type=int, default=100)
+    p.add_argument('--save_every', type=int, default=1000)
+    return p
+
+
+def decay_steps_for(lr, min_lr, num_total_steps=150000, decay_rate=0.96):
+    """(:166) -- note the reference always uses 150000 here, whatever the real step count."""
+    return (math.log(decay_rate) * num_total_steps) / math.log(min_lr * 1.0 / lr)
+
+
+def staircase_lr(lr, step, decay_steps, decay_rate=0.96):
+    """tf.train.exponential_decay(lr, step, int(decay_steps), decay_rate, staircase=True)  (:169)"""
+    return lr * decay_rate ** (step // int(decay_steps))
+
+
+class TrainStep(object):
+    """One tower: shared variables + Adam + (for world > 1) overlapped RCCL gradient averaging."""
+
+    def __init__(self, args, device, world=1, net=None):
+        self.args = args
+        self.device = device
+        self.world = world
+        self.net = net if net is not None else VGGRegressor(args.patch_size, args.use_batch_norm)
+        self.net = self.net.to(device).to(memory_format=torch.channels_last)
+        if world > 1:                                       # identical initial variables on every rank
+            for t in list(self.net.parameters()) + list(self.net.buffers()):
+                torch.distributed.broadcast(t.data, src=0)
+        self.decay_steps = decay_steps_for(args.lr, args.min_lr)
+        self.global_step = 0
+        self.averager = uh_dist.GradAverager(self.net, world)
+        kw = {}
+        if device.type == 'cuda':
+            kw['fused'] = True
+        self.opt = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=args.lr,
+                                    betas=(0.9, 0.999), eps=1e-8, **kw)
+        self.model_params = homography_model_params(
+            mode=args.mode, batch_size=int(args.batch_size / world), patch_size=args.patch_size,
+            img_h=args.img_h, img_w=args.img_w, loss_type=args.loss_type, use_batch_norm=args.use_batch_norm,
+            augment_list=args.augment_list, leftright_consistent_weight=args.leftright_consistent_weight)
+
+    def learning_rate(self):
+        return staircase_lr(self.args.lr, self.global_step, self.decay_steps)
+
+    def __call__(self, batch):
+        """sess.run([apply_grad_opt, ...]) of the hot loop (:333-353): forward, backward, average, Adam."""
+        lr = self.learning_rate()
+        for g in self.opt.param_groups:
+            g['lr'] = lr
+        self.averager.reset()
+        model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
+                                net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64)
+        model.loss.backward()
+        self.averager.finish()
+        self.opt.step()
+        self.global_step += 1
+        return model
+
+    def state_dict(self):
+        return {'net': self.net.state_dict(), 'opt': self.opt.state_dict(), 'global_step': self.global_step}
+
+    def load_state_dict(self, sd, retrain=False):
+        self.net.load_state_dict(sd['net'])
+        self.opt.load_state_dict(sd['opt'])
+        self.global_step = 0 if retrain else sd['global_step']        # (:314-317)
+
+
+def _ckpt_path(args):
+    prefix = args.loss_type + ''.join('_' + a for a in args.augment_list)
+    d = os.path.join(args.model_dir, prefix)
+    return d, os.path.join(d, args.model_name + '.pt')
+
+
+def train(args):
+    rank, world, local = uh_dist.init_from_env()
+    device = torch.device('cuda', local) if torch.cuda.is_available() else None
+    if device is None:
+        raise RuntimeError('training needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(device)
+    torch.manual_seed(args.seed)
+    step_fn = TrainStep(args, device, world)
+    ckpt_dir, ckpt = _ckpt_path(args)
+    if args.resume and os.path.exists(ckpt):
+        step_fn.load_state_dict(torch.load(ckpt, map_location=device), retrain=args.retrain)
+    start_step = step_fn.global_step
+    if rank == 0:
+        print('===> Decay steps:', step_fn.decay_steps)
+        print('===> Start step:', start_step, ' world size:', world)
+    B_local = args.batch_size // world
+    names = ['h_loss', 'rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss']
+    totals = torch.zeros(len(names), device=device)
+    batch = None
+    t0 = time.time()
+    for step in range(start_step, start_step + args.num_total_steps):
+        if batch is None or (step - start_step) % max(args.fresh_data_every, 1) == 0:
+            # every rank draws its own shard (seeded by step and rank) == tf.split of a global batch
+            batch = synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
+                                         seed=args.seed + step * world + rank, device=device)
+        model = step_fn(batch)
+        vals = uh_dist.all_reduce_mean_scalars([getattr(model, n) for n in names], world)
+        totals += torch.stack([v.detach() for v in vals])
+        if rank == 0 and step % args.log_every == 0:
+            n = step - start_step + 1
+            avg = (totals / n).tolist()
+            dt = time.time() - t0
+            print('Train: step %d  ' % step + ', '.join('%s %.6f' % (k, v) for k, v in zip(names, avg))
+                  + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9)),
+                  flush=True)
+        if rank == 0 and step and step % args.save_every == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+            torch.save(step_fn.state_dict(), ckpt)
+    if rank == 0:
+        os.makedirs(ckpt_dir, exist_ok=True)
+        torch.save(step_fn.state_dict(), ckpt)          # Save the final model (:389)
+    return step_fn
+
+
+class TestHomography(object):
+    """Test-mode loop (:391-580): mean corner error (bounded RMSE), failure rate and percentiles."""
+
+    def __init__(self, args, step_fn=None):
+        self.args = args
+        device = torch.device('cuda', 0)
+        args_t = argparse.Namespace(**vars(args)); args_t.mode = 'test'
+        self.step_fn = step_fn
+        net = step_fn.net if step_fn is not None else VGGRegressor(args.patch_size, args.use_batch_norm).to(device)
+        if step_fn is None:
+            _, ckpt = _ckpt_path(args)
+            if os.path.exists(ckpt):
+                net.load_state_dict(torch.load(ckpt, map_location=device)['net'])
+        self.net = net
+        self.device = device
+        self.params = homography_model_params(
+            mode='test', batch_size=args.batch_size, patch_size=args.patch_size, img_h=args.img_h,
+            img_w=args.img_w, loss_type=args.loss_type, use_batch_norm=args.use_batch_norm,
+            augment_list=args.augment_list, leftright_consistent_weight=args.leftright_consistent_weight)
+
+    def run(self):
+        a = self.args
+        steps_per_epoch = int(np.ceil(a.num_test_data / a.batch_size))
+        num_steps = 3 * steps_per_epoch                                   # (:400-401)
+        per_pair, total_fail, total_bounded = [], 0.0, 0.0
+        was_training = self.net.training
+        with torch.no_grad():
+            for step in range(num_steps):
+                batch = synthetic.make_batch(a.batch_size, a.img_h, a.img_w, a.patch_size, a.rho,
+                                             seed=10_000_000 + a.seed + step, device=self.device)
+                m = HomographyModel(self.params, *synthetic.model_args(batch), reuse_variables=True, net=self.net,
+                                    solve_f64=a.solve_f64)
+                total_bounded += float(m.bounded_h_loss)
+                total_fail += float(m.num_fail)
+                per_pair.append(torch.sqrt(torch.mean((m.pred_h4p - m.gt) ** 2, dim=1)).cpu())
+        self.net.train(was_training)
+        per_pair = torch.cat(per_pair).numpy()
+        res = {
+            'mean_corner_error': total_bounded / num_steps,
+            'fail_percent': 100.0 * total_fail / (num_steps * a.batch_size),
+            'percentiles': {q: float(np.percentile(per_pair, q)) for q in (30, 60, 100)},
+            'num_pairs': int(per_pair.size),
+        }
+        print('====> Result for RHO:', a.rho, ' loss ', a.loss_type)
+        print('|Average error: %.4f |Fail percent: %.3f' % (res['mean_corner_error'], res['fail_percent']))
+        return res
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.mode == 'train':
+        train(args)
+    else:
+        TestHomography(args).run()
+
+
+if __name__ == '__main__':
+    main()

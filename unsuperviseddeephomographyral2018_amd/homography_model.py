@@ -1,0 +1,260 @@
+"""HomographyModel -- host-side mirror of /root/reference/code/homography_model.py.
+
+Same namedtuple, same constructor signature, same stage methods (build_model, solve_DLT, transform,
+build_losses, build_summaries) and the same result attributes (pred_h4p, H_mat, pred_I2, h_loss,
+rec_loss, ssim_loss, l1_loss, l1_smooth_loss, ncc_loss, bounded_h_loss, num_fail), but eager on
+torch tensors (NHWC logical layout, as the reference's dataloader emits) instead of a TF1 graph.
+
+What runs where
+  * VGG regressor (homography_model.py:107-133): stock PyTorch-ROCm (MIOpen / hipBLASLt), channels_last.
+  * solve_DLT, transform, l1 loss (:169-269, :328): the HIP C-ABI library via ops.py -- no torch math.
+  * the monitoring losses (:136-166, :286-352): a handful of torch elementwise ops on [B,P,P,1].
+"""
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+# homography_model.py:12-22
+homography_model_params = namedtuple('parameters',
+                                     'mode,'
+                                     'batch_size,'
+                                     'patch_size,'
+                                     'img_w,'
+                                     'img_h,'
+                                     'loss_type,'
+                                     'use_batch_norm,'
+                                     'augment_list,'
+                                     'leftright_consistent_weight,'
+                                     )
+
+LOSS_TYPES = ('h_loss', 'rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss')
+
+
+def fspecial_gauss(size, sigma, device=None):
+    """MATLAB fspecial('gaussian') (homography_model.py:24-40); only used as the stored ssim_window."""
+    x, y = np.mgrid[-size // 2 + 1:size // 2 + 1, -size // 2 + 1:size // 2 + 1]
+    g = np.exp(-((x ** 2 + y ** 2) / (2.0 * sigma ** 2)))
+    return torch.tensor(g / g.sum(), dtype=torch.float32, device=device)
+
+
+class VGGRegressor(nn.Module):
+    """_vgg (homography_model.py:107-133): 4 blocks of 2x(pad1 + conv3x3 VALID + ReLU), channels
+    64,64 / 64,64 / 128,128 / 128,128, 2x2/2 max-pool after blocks 1-3, dropout(0.5) on conv4 and
+    fc1 when training, flatten (NHWC order) -> FC1024 ReLU -> FC8.  slim defaults: Xavier-uniform
+    weights, zero biases.  Optional BN keeps the reference's quirk: is_training is passed as the
+    *decay* (:93), i.e. decay=1 -> moving statistics never move (momentum 0 here)."""
+
+    def __init__(self, patch_size=128, use_batch_norm=False):
+        super().__init__()
+        chans = [(2, 64), (64, 64), (64, 64), (64, 64), (64, 128), (128, 128), (128, 128), (128, 128)]
+        self.convs = nn.ModuleList([nn.Conv2d(i, o, 3, stride=1, padding=1) for i, o in chans])
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.bns = nn.ModuleList([nn.BatchNorm2d(o, eps=1e-3, momentum=0.0) for _, o in chans])
+            for bn in self.bns:                      # slim.batch_norm default: center=True, scale=False
+                bn.weight.requires_grad_(False)
+        feat = patch_size // 8
+        self.fc1 = nn.Linear(feat * feat * 128, 1024)
+        self.fc2 = nn.Linear(1024, 8)
+        for m in list(self.convs) + [self.fc1, self.fc2]:
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.zeros_(m.bias)
+
+    def _conv(self, x, i):
+        x = F.relu(self.convs[i](x))
+        if self.use_batch_norm:
+            x = self.bns[i](x)
+        return x
+
+    def forward(self, model_input_nhwc):
+        # [B,P,P,2] NHWC -> NCHW-logical view with channels_last strides (no copy)
+        x = model_input_nhwc.permute(0, 3, 1, 2)
+        x = self._conv(self._conv(x, 0), 1)
+        x = F.max_pool2d(x, 2, 2)
+        x = self._conv(self._conv(x, 2), 3)
+        x = F.max_pool2d(x, 2, 2)
+        x = self._conv(self._conv(x, 4), 5)
+        x = F.max_pool2d(x, 2, 2)
+        x = self._conv(self._conv(x, 6), 7)
+        x = F.dropout(x, 0.5, self.training)
+        x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)          # slim.flatten of NHWC
+        x = F.dropout(F.relu(self.fc1(x)), 0.5, self.training)
+        return self.fc2(x)
+
+
+# TF keeps variables in the graph's variable scope; `reuse_variables=True` means "the tower shares the
+# variables created by the first tower".  Eager torch needs an owner: this registry plays that role.
+_VARIABLE_SCOPE = {}
+
+
+def get_variables(scope='model'):
+    """The nn.Module holding the variables of variable_scope('model') (for the optimizer / DP)."""
+    return _VARIABLE_SCOPE[scope]
+
+
+def reset_variables():
+    _VARIABLE_SCOPE.clear()
+
+
+class HomographyModel(object):
+    def __init__(self, args, I1, I2, I1_aug, I2_aug, I_aug, I_prime_aug, h4p, gt, patch_indices,
+                 reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False):
+        self.params = args
+        self.mode = args.mode
+        self.is_training = True if self.mode == 'train' else False
+        self.I1 = I1
+        self.I2 = I2
+        self.I1_aug = I1_aug
+        self.I2_aug = I2_aug
+        # I and I_prime are augmented by default
+        self.I = I_aug
+        self.I_prime = I_prime_aug
+        self.pts_1 = h4p
+        self.gt = gt
+        self.use_batch_norm = args.use_batch_norm
+        self.patch_indices = patch_indices
+        self.reuse_variables = reuse_variables
+        self.model_collection = ['model_' + str(model_index)]
+        # MI355X-side switches (not in the reference): fused patch kernel for the l1 path, f64 DLT solve
+        self.fused_patch = fused_patch
+        self.solve_f64 = solve_f64
+        if args.loss_type not in LOSS_TYPES:
+            raise ValueError('===> Loss type does not exist! ' + str(args.loss_type))
+        # Constants used for the spatial transformer (homography_model.py:63-72): live in ops.m_and_minv
+        self.M, self.M_inv = ops.m_and_minv(self.params.img_w, self.params.img_h)
+        # batch_indices_tensor (:74-76) is folded into the gather kernel (per-image base offset)
+        self.ssim_window = fspecial_gauss(size=3, sigma=0.5, device=I_aug.device)
+
+        if net is not None:
+            self.net = net
+        elif reuse_variables:
+            if 'model' not in _VARIABLE_SCOPE:
+                raise ValueError("reuse_variables=True but variable_scope('model') holds no variables yet")
+            self.net = _VARIABLE_SCOPE['model']
+        else:
+            self.net = VGGRegressor(args.patch_size, args.use_batch_norm).to(I_aug.device)
+            self.net = self.net.to(memory_format=torch.channels_last)
+            _VARIABLE_SCOPE['model'] = self.net
+        self.net.train(self.is_training)
+        # with the supervised loss the DLT/warp only feed stop_gradient monitors (:286-296)
+        self._hot_grad = args.loss_type != 'h_loss' and torch.is_grad_enabled()
+
+        self.build_model()
+        self.solve_DLT()
+        self.transform()
+        self.build_losses()
+        self.build_summaries()
+
+    # ---- homography_model.py:354-361 ------------------------------------------------------------
+    def build_model(self):
+        self.model_input = torch.cat([self.I1_aug, self.I2_aug], 3)
+        self.pts_1_tile = self.pts_1.unsqueeze(2)                  # BATCH_SIZE x 8 x 1
+        self._vgg()
+
+    def _vgg(self):
+        self.pred_h4p = self.net(self.model_input)                # BATCH_SIZE x 8
+
+    # ---- homography_model.py:169-250 (+ the theta fold of :254) ------------------------------------
+    def solve_DLT(self):
+        with torch.set_grad_enabled(self._hot_grad):
+            self.H_mat, self._theta = ops.solve_dlt(self.pts_1, self.pred_h4p, self.params.img_w,
+                                                    self.params.img_h, solve_f64=self.solve_f64)
+
+    # ---- homography_model.py:252-269 ----------------------------------------------------------------
+    def transform(self):
+        with torch.set_grad_enabled(self._hot_grad):
+            self._transform()
+
+    def _transform(self):
+        P = self.params.patch_size
+        out_size = (self.params.img_h, self.params.img_w)
+        if self.fused_patch and self.params.loss_type == 'l1_loss':
+            # one kernel: sample -> gray -> patch -> |.| -> mean, and d/dtheta; warped frame never exists
+            self._l1_fused, self.pred_I2 = ops.warp_patch_l1(self.I, self._theta, self.I2_aug,
+                                                             self.patch_indices, P)
+            return
+        self._l1_fused = None
+        warped_images, _ = ops.transformer(self.I, self._theta, out_size, with_condition=False)
+        self.warped_images = warped_images
+        self.pred_I2 = ops.gray_patch_gather(warped_images, self.patch_indices, P)
+
+    # ---- homography_model.py:136-166 ----------------------------------------------------------------
+    def _L1_smooth_loss(self, x, y):
+        abs_diff = torch.abs(x - y)
+        return torch.mean(torch.where(abs_diff < 1, 0.5 * abs_diff * abs_diff, abs_diff - 0.5))
+
+    def _SSIM_loss(self, x, y, size=3):
+        C1 = 0.01 ** 2
+        C2 = 0.03 ** 2
+        x = x.permute(0, 3, 1, 2); y = y.permute(0, 3, 1, 2)
+        pool = lambda v: F.avg_pool2d(v, size, 1)
+        mu_x = pool(x); mu_y = pool(y)
+        sigma_x = pool(x ** 2) - mu_x ** 2
+        sigma_y = pool(y ** 2) - mu_y ** 2
+        sigma_xy = pool(x * y) - mu_x * mu_y
+        SSIM_n = (2 * mu_x * mu_y + C1) * (2 * sigma_xy + C2)
+        SSIM_d = (mu_x ** 2 + mu_y ** 2 + C1) * (sigma_x + sigma_y + C2)
+        SSIM = SSIM_n / SSIM_d
+        return torch.clamp((1 - SSIM) / 2, 0, 1).permute(0, 2, 3, 1)
+
+    def _NCC_loss(self, x, y):
+        len_x = torch.sqrt(torch.sum(x * x))
+        len_y = torch.sqrt(torch.sum(y * y))
+        return torch.sqrt(torch.sum((x / len_x - y / len_y) ** 2))
+
+    # ---- homography_model.py:271-352 ----------------------------------------------------------------
+    def build_losses(self):
+        I2 = self.I2_aug
+        lt = self.params.loss_type
+
+        if self.params.mode == 'test':
+            with torch.no_grad():
+                batch_h_loss = torch.sqrt(torch.mean((self.pred_h4p - self.gt) ** 2, dim=1))
+                h_loss_identity = torch.sqrt(torch.mean(self.gt ** 2, dim=1))
+                is_failure = (batch_h_loss >= h_loss_identity).float()
+                self.num_fail = torch.sum(is_failure)
+                # If it is a fail, use identity matrix
+                self.bounded_h_loss = torch.mean(batch_h_loss * (1 - is_failure) + is_failure * h_loss_identity)
+
+        def maybe_stop(active, fn):
+            if active:
+                return fn()
+            with torch.no_grad():
+                return fn()
+
+        pred = self.pred_I2
+        pred_m = pred.detach()                       # monitors never carry gradient
+        self.h_loss = maybe_stop(lt == 'h_loss', lambda: torch.sqrt(torch.mean((self.pred_h4p - self.gt) ** 2)))
+        self.rec_loss = maybe_stop(lt == 'rec_loss', lambda: torch.sqrt(torch.mean(
+            ((pred if lt == 'rec_loss' else pred_m) - I2) ** 2)))
+        self.ssim_loss = maybe_stop(lt == 'ssim_loss', lambda: torch.mean(self._SSIM_loss(
+            pred if lt == 'ssim_loss' else pred_m, I2)))
+        if lt == 'l1_loss':
+            # the photometric L1 of the hot path: HIP reduction kernel (or the fused patch kernel's output)
+            self.l1_loss = self._l1_fused if self._l1_fused is not None else ops.l1_loss(pred, I2)
+        else:
+            with torch.no_grad():
+                self.l1_loss = ops.l1_loss(pred_m, I2)
+        self.l1_smooth_loss = maybe_stop(lt == 'l1_smooth_loss', lambda: self._L1_smooth_loss(
+            pred if lt == 'l1_smooth_loss' else pred_m, I2))
+        self.ncc_loss = maybe_stop(lt == 'ncc_loss', lambda: self._NCC_loss(
+            I2, pred if lt == 'ncc_loss' else pred_m))
+
+    @property
+    def loss(self):
+        """The tensor the trainer differentiates (homography_CNN_synthetic.py:251-265)."""
+        return getattr(self, self.params.loss_type)
+
+    # ---- homography_model.py:363-376 ----------------------------------------------------------------
+    def build_summaries(self):
+        # tf.summary.image(..., max_outputs=1): keep references to the first sample of each stream
+        self.summaries = {
+            'I': self.I[:1], 'I_prime': self.I_prime[:1] if self.I_prime is not None else None,
+            'I1_aug': self.I1_aug[:1], 'I2_aug': self.I2_aug[:1], 'I1': self.I1[:1], 'I2': self.I2[:1],
+            'pred_I2': self.pred_I2[:1].detach(),
+        }
