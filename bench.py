@@ -46,8 +46,9 @@ def parse():
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
     ap.add_argument('--cpu_baseline', type=int, default=1)
-    ap.add_argument('--cpu_sample_pairs', type=int, default=16)
+    ap.add_argument('--cpu_sample_pairs', type=int, default=8)
     ap.add_argument('--cpu_sample_steps', type=int, default=2)
+    ap.add_argument('--cpu_threads', type=int, default=32, help='host threads for the CPU leg (capped at nproc)')
     return ap.parse_args()
 
 
@@ -56,7 +57,7 @@ def cpu_baseline(args):
     autograd backward, Adam) on a bounded sample: `cpu_sample_pairs` pairs x `cpu_sample_steps` steps."""
     from oracle import hotpath_torch as OT
     from unsuperviseddeephomographyral2018_amd.homography_model import VGGRegressor
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, args.cpu_threads)     # small ops: more threads only add contention
     torch.set_num_threads(cores)
     B, H, W, P = args.cpu_sample_pairs, args.img_h, args.img_w, args.patch_size
     g = torch.Generator().manual_seed(0)
@@ -84,7 +85,8 @@ def cpu_baseline(args):
     return {'value': round(B * args.cpu_sample_steps / dt, 2), 'unit': 'image-pairs/s', 'cores': cores,
             'kind': 'port',
             'sample': '%d train steps of %d pairs (%dx%d, P=%d), torch-CPU op-graph restatement of the TF graph '
-                      '+ same VGG + Adam, %d threads, %.1f s' % (args.cpu_sample_steps, B, H, W, P, cores, dt)}
+                      '+ same VGG + Adam, %d threads of %d host cores, %.1f s' % (args.cpu_sample_steps, B, H, W, P, cores,
+                                                                                 os.cpu_count() or 1, dt)}
 
 
 def north_star_point(device, args, B=128, iters=30):

@@ -334,7 +334,11 @@ def test_full_size_properties(ops, dev):
     ops.transformer(U, t1, (H, W))[0].backward(g); ops.transformer(U, t2, (H, W))[0].backward(g)
     assert torch.equal(t1.grad, t2.grad)
     # (5) dTheta of the first two images vs the f64 closed form (full-frame random dOut)
-    refd = O.transformer_backward(d['I'], th_np.astype(np.float64), g[:2].cpu().numpy(), (H, W), np.float64)
+    #     evaluated at the f32 sample positions: with an incoherent (white-noise) dOut the sum is a random
+    #     walk and one f32-vs-f64 floor() flip moves it by ~1/sqrt(N) ~ 3e-3 (see the oracle docstring);
+    #     the all-f64 comparison is made on coherent dOut in test_warp_backward_dtheta_vs_oracle and
+    #     test_full_size_fused_patch_vs_oracle.
+    refd = O.transformer_backward(d['I'], th_np, g[:2].cpu().numpy(), (H, W), np.float64, coord_dtype=np.float32)
     got = t1.grad[:2].cpu().numpy().reshape(2, 3, 3)
     for k in range(2):
         assert relerr(got[k], refd[k]) < 1e-4

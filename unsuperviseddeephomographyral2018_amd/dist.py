@@ -67,7 +67,12 @@ class GradAverager(object):
             flat = torch.zeros(total, dtype=plist[0][1].dtype, device=plist[0][1].device)
             off = 0
             for _, p in plist:
-                p.grad = flat[off:off + p.numel()].view_as(p)        # persistent view: no pack/unpack
+                # persistent view with the PARAMETER's strides (conv weights are channels_last): no
+                # pack/unpack, and fused Adam requires grad/param layouts to match
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if not dense:
+                    raise RuntimeError('GradAverager needs dense (contiguous or channels_last) parameters')
+                p.grad = torch.as_strided(flat, p.size(), p.stride(), off)
                 off += p.numel()
             bucket = {'flat': flat, 'params': [p for _, p in plist], 'pending': 0}
             self.buckets.append(bucket)
