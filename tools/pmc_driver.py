@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""Minimal launch loop for rocprofv3 passes: N x (warp_fwd, warp_bwd[, fused patch]) at one config."""
+"""Minimal launch loop for rocprofv3 passes: N x (calibration copy, warp_fwd, warp_bwd[, fused patch]) at one
+config.  The calibration copy (torch `out.copy_(U)`: a 16 B/lane streaming kernel moving exactly the bytes
+warp_fwd's signature moves) gives the gfx950 correction factor of FETCH_SIZE / WRITE_SIZE for this run
+(MI355X_MICROARCH.md, "HBM": FETCH_SIZE under-reports wide streaming reads by 2x; calibrate in your own run)."""
 import argparse, ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +25,7 @@ nb2 = lib.uh_warp_patch_l1_workspace_bytes(B, P * P); ws2 = torch.empty(nb2 // 4
 I2f = I2.reshape(B, -1).contiguous()
 torch.cuda.synchronize()
 for _ in range(a.iters):
+    out.copy_(U)
     lib.uh_warp_forward(p(U), p(theta), p(out), None, B, H, W, 3, H, W, None)
     lib.uh_warp_backward(p(U), p(theta), p(dOut), p(dT), None, p(ws), nb, B, H, W, 3, H, W, None)
     if a.fused:
