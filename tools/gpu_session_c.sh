@@ -1,0 +1,12 @@
+#!/bin/bash
+# GPU session C: A/B of kernel variants (developer).  $1 = list of variant names ("" = shipped lib)
+mkdir -p gpurun_out; cd /root/repo
+V=unsuperviseddeephomographyral2018_amd/lib/variants
+CFG=${CFG:-"128,240,320,128,45;128,480,640,128,64"}
+timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -3 > gpurun_out/pytest_c.log
+: > gpurun_out/micro_c.log
+timeout 120 python tools/microbench.py --iters 50 --configs "$CFG" 2>/dev/null >> gpurun_out/micro_c.log
+for n in $1; do
+  UH_LIB_PATH=$V/libuh_$n.so timeout 120 python tools/microbench.py --iters 50 --configs "$CFG" 2>/dev/null >> gpurun_out/micro_c.log
+done
+echo done

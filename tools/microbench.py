@@ -49,6 +49,8 @@ def run(B, H, W, P, rho, iters, dev):
     U, pts1, h4p, idx, I2 = make_inputs(B, H, W, P, rho, dev)
     _, theta = ops.solve_dlt(pts1, h4p, img_w=W, img_h=H)
     theta = theta.detach()
+    if os.environ.get('UH_IDENTITY_THETA'):
+        theta = torch.eye(3, device=dev).reshape(1, 9).repeat(B, 1).contiguous()
     dOut = torch.randn_like(U)
     bytes_fwd = 2 * B * H * W * 3 * 4
     res = {'B': B, 'H': H, 'W': W, 'alg_MB_fwd': bytes_fwd / 1e6}
@@ -106,7 +108,7 @@ def main():
     for cfg in args.configs.split(';'):
         B, H, W, P, rho = (int(v) for v in cfg.split(','))
         r = run(B, H, W, P, rho, args.iters, dev)
-        r['lib'] = os.path.basename(_lib.LIB_PATH)
+        r['lib'] = os.path.basename(_lib.LIB_PATH); r['identity'] = bool(os.environ.get('UH_IDENTITY_THETA'))
         print(json.dumps(r), flush=True)
 
 

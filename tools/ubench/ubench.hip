@@ -130,6 +130,10 @@ __global__ __launch_bounds__(256) void k_lds(unsigned* out, int shift) {
     for (int it = 0; it < MITERS * 4; ++it) {
         if constexpr (WORDS == 1) { unsigned v; asm volatile("ds_read_b32 %0, %1\ns_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p)); acc += v; }
         else if constexpr (WORDS == 3) { u32x3 v; asm volatile("ds_read_b96 %0, %1\ns_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p)); acc += v.x ^ v.z; }
+        else if constexpr (WORDS == 2) { u32x2 v; asm volatile("ds_read_b64 %0, %1\ns_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p)); acc += v.x ^ v.y; }
+        else if constexpr (WORDS == 12) { u32x2 v; asm volatile("ds_read2_b32 %0, %1 offset1:1\ns_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p)); acc += v.x ^ v.y; }
+        else if constexpr (WORDS == 13) { u32x2 v; unsigned w; asm volatile("ds_read2_b32 %0, %2 offset1:1\nds_read_b32 %1, %2 offset:8\ns_waitcnt lgkmcnt(0)" : "=v"(v), "=v"(w) : "v"((unsigned)(size_t)p)); acc += v.x ^ v.y ^ w; }
+        else if constexpr (WORDS == 33) { unsigned a, b, c; asm volatile("ds_read_b32 %0, %3\nds_read_b32 %1, %3 offset:4\nds_read_b32 %2, %3 offset:8\ns_waitcnt lgkmcnt(0)" : "=v"(a), "=v"(b), "=v"(c) : "v"((unsigned)(size_t)p)); acc += a ^ b ^ c; }
         else { u32x4 v; asm volatile("ds_read_b128 %0, %1\ns_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p)); acc += v.x ^ v.w; }
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
@@ -183,5 +187,9 @@ int main() {
     RUN_LDS((k_lds<1, 1>), 1, "lds b32 stride 1", 0) RUN_LDS((k_lds<1, 3>), 1, "lds b32 stride 3", 0)
     RUN_LDS((k_lds<3, 3>), 3, "lds b96 stride 3", 0) RUN_LDS((k_lds<3, 3>), 3, "lds b96 stride 3 shift 1", 1)
     RUN_LDS((k_lds<4, 4>), 4, "lds b128 stride 4", 0)
+    RUN_LDS((k_lds<4, 3>), 4, "lds b128 stride 3 (4B align)", 0) RUN_LDS((k_lds<4, 3>), 4, "lds b128 stride 3 shift 1", 1)
+    RUN_LDS((k_lds<2, 2>), 2, "lds b64 stride 2", 0) RUN_LDS((k_lds<2, 3>), 2, "lds b64 stride 3 (4B align)", 0)
+    RUN_LDS((k_lds<12, 3>), 2, "lds read2_b32 stride 3", 0) RUN_LDS((k_lds<13, 3>), 3, "lds read2+read stride 3", 0)
+    RUN_LDS((k_lds<33, 3>), 3, "lds 3x b32 stride 3", 0)
     return 0;
 }

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../unsuperviseddeephomographyral2018_amd/csrc"
 OUT=../lib/variants; mkdir -p $OUT
 while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden $flags \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -fvisibility=hidden $flags \
      uh_dlt.hip uh_warp.hip uh_misc.hip uh_patch.hip -o $OUT/libuh_$name.so &
 done
 wait

@@ -15,7 +15,7 @@ namespace uh {
 struct Theta { float a[9]; };          // row-major 3x3, passed in SGPRs
 
 // tf.linspace(-1, 1, n)[i] as TF1 evaluates it: start + step*i, step = (stop-start)/(n-1)   (:162-165)
-__device__ __forceinline__ float lin_step(int n) { return n > 1 ? 2.0f / (float)(n - 1) : 0.0f; }
+__host__ __device__ __forceinline__ float lin_step(int n) { return n > 1 ? 2.0f / (float)(n - 1) : 0.0f; }
 __device__ __forceinline__ float lin_at(float step, int i) { return -1.0f + step * (float)i; }
 
 // tf.cast(float -> int32) as x86 does it (cvttss2si): NaN / out of range -> INT32_MIN.  `f` is
@@ -63,6 +63,212 @@ __device__ __forceinline__ float blend(const Sample& s, float Ia, float Ib, floa
     return ((wa * Ia + wb * Ib) + wc * Ic) + wd * Id;
 }
 
+// ================================================================================================
+// Lean sampling path (what the bandwidth kernels use).  Same arithmetic as make_sample()/blend() --
+// bit-identical results on every input the reference handles (tests/test_gpu_parity.py checks the two
+// against each other and against the f32 oracle) -- but re-expressed for the gfx950 VALU, whose issue
+// cost per wave64 instruction was measured with tools/ubench (profiles/r01_gfx950_instruction_costs.txt):
+//   2 cycles: v_add/sub/mul/fma_f32, v_add_u32, v_and, v_mov      4 cycles: everything else (cmp, cndmask,
+//   cvt, floor, med3, min/max, lshl, mul24/mad24, 64-bit adds, v_div_*)      8 cycles: v_rcp_f32
+// The first kernels spent ~500 VALU cycles per 64 output pixels and were VALU-bound, not HBM-bound
+// (SQ_ACTIVE_INST_VALU = 70 % of the kernel's duration).  The diet:
+//   * ONE reciprocal shared by xs/t and ys/t: the exact Newton/fma sequence LLVM emits for an IEEE f32
+//     division (rcp, 2 fma, then per numerator mul + 4 fma), minus v_div_scale/v_div_fixup, which are
+//     identities here because the eps-guard bounds |t| >= 1e-7 (no denormal / overflow scaling) --
+//     68 -> 32 cycles, same bits;
+//   * clip in the float domain (v_med3_f32) with the x86 cvttss2si overflow rule folded into one
+//     compare+select, instead of cvt -> int compare -> int clamp -> cvt back;
+//   * byte offsets formed in f32 (exact below 2^24) and converted once; 32-bit offsets into a buffer
+//     resource (no 64-bit address arithmetic, no sign extension).
+// ================================================================================================
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int C> struct Pix { float v[C]; };
+
+// raw buffer resource over [ptr, ptr + bytes): 32-bit byte offsets, out-of-range reads return 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
+}
+
+template <int C>
+__device__ __forceinline__ Pix<C> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    Pix<C> p;
+    if constexpr (C == 1) {
+        p.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    } else if constexpr (C == 2) {
+        u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        p.v[0] = __uint_as_float(t.x); p.v[1] = __uint_as_float(t.y);
+    } else if constexpr (C == 3) {
+        u32x3_t t = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0);
+        p.v[0] = __uint_as_float(t.x); p.v[1] = __uint_as_float(t.y); p.v[2] = __uint_as_float(t.z);
+    } else {
+        u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        p.v[0] = __uint_as_float(t.x); p.v[1] = __uint_as_float(t.y); p.v[2] = __uint_as_float(t.z);
+        p.v[3] = __uint_as_float(t.w);
+    }
+    return p;
+}
+
+template <int C>
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const Pix<C>& p) {
+    if constexpr (C == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p.v[0]), r, voff, soff, 0);
+    } else if constexpr (C == 2) {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(p.v[0]), __float_as_uint(p.v[1])}, r, voff, soff, 0);
+    } else if constexpr (C == 3) {
+        __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{__float_as_uint(p.v[0]), __float_as_uint(p.v[1]),
+                                                      __float_as_uint(p.v[2])}, r, voff, soff, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(p.v[0]), __float_as_uint(p.v[1]),
+                                                       __float_as_uint(p.v[2]), __float_as_uint(p.v[3])}, r, voff, soff, 0);
+    }
+}
+
+// Per-image constants of the source frame, prepared once per wave (uniform -> SGPRs).
+struct SrcGeom {
+    float Wf, Hf;           // (float)W, (float)H                    (:97-98)
+    float Wm1, Hm1;         // clip bounds W-1, H-1                  (:106-109)
+    float rowB, pixB;       // bytes per source row / per pixel, as f32 (exact: image < 2^24 bytes on this path)
+    int   rowBi, pixBi;     // the same as integers (large-image path)
+};
+template <int C>
+__device__ __forceinline__ SrcGeom make_geom(int W, int H) {
+    SrcGeom g;
+    g.Wf = (float)W; g.Hf = (float)H; g.Wm1 = (float)(W - 1); g.Hm1 = (float)(H - 1);
+    g.rowBi = W * C * 4; g.pixBi = C * 4; g.rowB = (float)g.rowBi; g.pixB = (float)g.pixBi;
+    return g;
+}
+
+// One sample, before addressing: clipped integer corners (as exact f32), 1-D weights, and what the
+// backward needs.
+struct Coord {
+    float x0f, x1f, y0f, y1f;       // clipped corners                                          (:106-109)
+    float ax1, ax0, ay1, ay0;       // x1f-x, x-x0f, y1f-y, y-y0f                               (:130-137)
+    float xs, ys, t, rt;            // T_g rows after the eps-guard, and the refined reciprocal of t
+};
+// byte offsets of the four taps: (y0,x0) (y1,x0) (y0,x1) (y1,x1)
+struct TapOff { unsigned oa, ob, oc, od; };
+struct Tap : TapOff {
+    float ax1, ax0, ay1, ay0;
+    float xs, ys, t, rt;
+};
+
+// floor + clip of one coordinate, x86 cast semantics included:
+//   floor(v) >= 2^31 or NaN -> cvttss2si gives INT32_MIN -> both corners clip to 0
+//   floor(v) <  -2^31       -> INT32_MIN as well        -> both corners clip to 0  (med3 does that already)
+__device__ __forceinline__ void clip_pair(float v, float hi, float& c0, float& c1) {
+    float fl = floorf(v);                                                                   // (:101,103)
+    fl = (fl < 2147483648.0f) ? fl : -1.0f;
+    c0 = __builtin_amdgcn_fmed3f(fl, 0.0f, hi);                                             // (:106,108)
+    c1 = __builtin_amdgcn_fmed3f(fl + 1.0f, 0.0f, hi);                                      // (:107,109)
+}
+
+// A0/A3/A6 = theta[0]*gx, theta[3]*gx, theta[6]*gx (hoisted: gx is fixed per lane); gy varies per row.
+__device__ __forceinline__ Coord make_coord(const Theta& th, float A0, float A3, float A6, float gy, const SrcGeom& g) {
+    Coord s;
+    s.xs = (A0 + th.a[1] * gy) + th.a[2];                                                   // (:213)
+    s.ys = (A3 + th.a[4] * gy) + th.a[5];
+    float t = (A6 + th.a[7] * gy) + th.a[8];
+    t = (fabsf(t) >= 1e-7f) ? t : t + 1e-6f;         // == t + 1e-6*(1 - [|t| >= 1e-7])        (:230-234)
+    s.t = t;
+    // xs/t and ys/t, IEEE-exact, one shared reciprocal (see the header comment)
+    const float y0 = __builtin_amdgcn_rcpf(t);
+    const float e0 = __builtin_fmaf(-t, y0, 1.0f);
+    const float y1 = __builtin_fmaf(e0, y0, y0);
+    s.rt = y1;
+    float q, r;
+    q = s.xs * y1; r = __builtin_fmaf(-t, q, s.xs); q = __builtin_fmaf(r, y1, q);
+    r = __builtin_fmaf(-t, q, s.xs); const float xn = __builtin_fmaf(r, y1, q);             // (:239)
+    q = s.ys * y1; r = __builtin_fmaf(-t, q, s.ys); q = __builtin_fmaf(r, y1, q);
+    r = __builtin_fmaf(-t, q, s.ys); const float yn = __builtin_fmaf(r, y1, q);             // (:240)
+    const float x = ((xn + 1.0f) * g.Wf) * 0.5f;     // /2 == *0.5 exactly                      (:97)
+    const float y = ((yn + 1.0f) * g.Hf) * 0.5f;                                            // (:98)
+    clip_pair(x, g.Wm1, s.x0f, s.x1f);
+    clip_pair(y, g.Hm1, s.y0f, s.y1f);
+    s.ax1 = s.x1f - x;  s.ax0 = x - s.x0f;                                                  // (:130-137)
+    s.ay1 = s.y1f - y;  s.ay0 = y - s.y0f;
+    return s;
+}
+
+// tap offsets inside the image in global memory
+template <bool SMALL>
+__device__ __forceinline__ TapOff global_offsets(const Coord& c, const SrcGeom& g) {
+    TapOff o;
+    if constexpr (SMALL) {      // every product below is an exact small integer in f32
+        const float xa = c.x0f * g.pixB, xc = c.x1f * g.pixB;
+        o.oa = (unsigned)__builtin_fmaf(c.y0f, g.rowB, xa);
+        o.ob = (unsigned)__builtin_fmaf(c.y1f, g.rowB, xa);
+        o.oc = (unsigned)__builtin_fmaf(c.y0f, g.rowB, xc);
+        o.od = (unsigned)__builtin_fmaf(c.y1f, g.rowB, xc);
+    } else {
+        const unsigned xa = (unsigned)c.x0f * (unsigned)g.pixBi, xc = (unsigned)c.x1f * (unsigned)g.pixBi;
+        const unsigned ra = (unsigned)c.y0f * (unsigned)g.rowBi, rb = (unsigned)c.y1f * (unsigned)g.rowBi;
+        o.oa = ra + xa; o.ob = rb + xa; o.oc = ra + xc; o.od = rb + xc;
+    }
+    return o;
+}
+
+// tap offsets inside a staged copy of the source rectangle [bx0..] x [by0..] with row pitch `pitch` bytes;
+// nbase = -(by0*pitch + bx0*pixB).  All quantities are exact small integers in f32 (region <= 64 KB).
+__device__ __forceinline__ TapOff staged_offsets(const Coord& c, float pitch, float pixB, float nbase) {
+    TapOff o;
+    const float xa = __builtin_fmaf(c.x0f, pixB, nbase), xc = __builtin_fmaf(c.x1f, pixB, nbase);
+    o.oa = (unsigned)__builtin_fmaf(c.y0f, pitch, xa);
+    o.ob = (unsigned)__builtin_fmaf(c.y1f, pitch, xa);
+    o.oc = (unsigned)__builtin_fmaf(c.y0f, pitch, xc);
+    o.od = (unsigned)__builtin_fmaf(c.y1f, pitch, xc);
+    return o;
+}
+
+template <int C, bool SMALL>
+__device__ __forceinline__ Tap make_tap(const Theta& th, float A0, float A3, float A6, float gy, const SrcGeom& g) {
+    const Coord c = make_coord(th, A0, A3, A6, gy, g);
+    Tap s;
+    static_cast<TapOff&>(s) = global_offsets<SMALL>(c, g);
+    s.ax1 = c.ax1; s.ax0 = c.ax0; s.ay1 = c.ay1; s.ay0 = c.ay0;
+    s.xs = c.xs; s.ys = c.ys; s.t = c.t; s.rt = c.rt;
+    return s;
+}
+
+// one pixel out of LDS at a 4-byte-aligned byte offset.  12-byte pixels are read as ds_read2_b32 + ds_read_b32:
+// on gfx950 a b64/b96/b128 LDS read that is not naturally aligned is serialised lane by lane (64 cycles, measured).
+template <int C>
+__device__ __forceinline__ Pix<C> lds_load(const unsigned char* lds, unsigned off) {
+    Pix<C> p;
+    const float* q = reinterpret_cast<const float*>(lds + off);
+#pragma unroll
+    for (int c = 0; c < C; ++c) p.v[c] = q[c];
+    return p;
+}
+
+// wave-wide min / max of NON-NEGATIVE integers (DPP butterflies, each step one fused v_min/max_i32_dpp:
+// lanes whose row is masked or whose source is invalid take the identity `OLD`), result wave-uniform.
+template <int CTRL, int ROW_MASK, int OLD>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(OLD, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_min_nonneg(int v) {
+    constexpr int ID = 0x7fffffff;
+    v = min(v, dpp_i32<0xB1, 0xf, ID>(v)); v = min(v, dpp_i32<0x4E, 0xf, ID>(v));
+    v = min(v, dpp_i32<0x141, 0xf, ID>(v)); v = min(v, dpp_i32<0x140, 0xf, ID>(v));
+    v = min(v, dpp_i32<0x142, 0xa, ID>(v)); v = min(v, dpp_i32<0x143, 0xc, ID>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+    v = max(v, dpp_i32<0xB1, 0xf, 0>(v)); v = max(v, dpp_i32<0x4E, 0xf, 0>(v));
+    v = max(v, dpp_i32<0x141, 0xf, 0>(v)); v = max(v, dpp_i32<0x140, 0xf, 0>(v));
+    v = max(v, dpp_i32<0x142, 0xa, 0>(v)); v = max(v, dpp_i32<0x143, 0xc, 0>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ((wa*Ia + wb*Ib) + wc*Ic) + wd*Id   -- tf.add_n order                                      (:134-138)
+__device__ __forceinline__ float blend4(float wa, float wb, float wc, float wd, float Ia, float Ib, float Ic, float Id) {
+    return ((wa * Ia + wb * Ib) + wc * Ic) + wd * Id;
+}
+
 // ---- XCD-aware block remap -------------------------------------------------------------------
 // The dispatcher places block b on XCD b % 8.  Give every XCD one CONTIGUOUS range of virtual block
 // ids so that the tiles of one image (which share source rows) meet in one 4 MiB L2.  Bijective for
@@ -77,11 +283,39 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 }
 
 // ---- wave / block reductions -------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
+// f32: DPP butterfly inside each row of 16 lanes, then row_bcast15 / row_bcast31 (gfx9 DPP controls) --
+// six v_add_f32_dpp, no LDS traffic (a __shfl_down tree is six ds_bpermute_b32 round trips).  The total is
+// returned wave-uniform (v_readlane of lane 63).  Fixed order -> bit-reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f32<0xB1, 0xf>(v);      // quad_perm:[1,0,3,2]
+    v += dpp_f32<0x4E, 0xf>(v);      // quad_perm:[2,3,0,1]
+    v += dpp_f32<0x141, 0xf>(v);     // row_half_mirror
+    v += dpp_f32<0x140, 0xf>(v);     // row_mirror      -> every lane holds its row's sum
+    v += dpp_f32<0x142, 0xa>(v);     // row_bcast:15    -> rows 1,3 += rows 0,2
+    v += dpp_f32<0x143, 0xc>(v);     // row_bcast:31    -> rows 2,3 += row 1
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// Sum inside each row of 16 lanes only (4 fused v_add_f32_dpp); every lane of a row ends up with its
+// row's sum.  Block reductions finish the 4 rows x NWAVE waves through LDS.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1, 0xf>(v);
+    v += dpp_f32<0x4E, 0xf>(v);
+    v += dpp_f32<0x141, 0xf>(v);
+    v += dpp_f32<0x140, 0xf>(v);
+    return v;
+}
+// f64 (tiny finishing kernels only): shuffle tree, total broadcast from lane 0
+__device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, UH_WAVE);
-    return v;    // valid in lane 0
+    return __shfl(v, 0, UH_WAVE);
 }
+
+// wave index of this thread as a scalar (threadIdx.x >> 6 is wave-uniform but the compiler cannot know)
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 }  // namespace uh

@@ -19,72 +19,109 @@ constexpr int PPT = 4;             // patch pixels per thread (amortises the blo
 constexpr int PB = 256 * PPT;      // patch pixels per block
 constexpr int NACC = 10;           // 9 dTheta sums + 1 |diff| sum
 
-template <int C, bool WANT_GRAD>
+// flat index -> (row, col) without an integer division: q = trunc(idx * (1/W)) is within 1 of the true
+// quotient for idx < 2^24; one fix-up step makes it exact.  (Large images take the '/' path.)
+template <bool SMALL>
+__device__ __forceinline__ void split_index(int idx, int W, float invW, int& row, int& col) {
+    if constexpr (SMALL) {
+        int q = (int)((float)idx * invW);
+        int r = idx - q * W;
+        if (r < 0) { q -= 1; r += W; }
+        if (r >= W) { q += 1; r -= W; }
+        row = q; col = r;
+    } else {
+        row = idx / W; col = idx - row * W;
+    }
+}
+
+template <int C, bool WANT_GRAD, bool SMALL>
 __global__ __launch_bounds__(256) void warp_patch_l1_kernel(
         const float* __restrict__ U, const float* __restrict__ theta, const float* __restrict__ I2,
         const int* __restrict__ patch_idx, float* __restrict__ pred, float* __restrict__ partial,
-        int H, int W, int PP, int blocks_per_image, unsigned nblk) {
-    __shared__ float red[4][NACC];
+        int H, int W, float sx, float sy, float invW, int PP, int blocks_per_image, unsigned nblk) {
+    __shared__ float red[NACC][16];
     const unsigned v = xcd_remap(blockIdx.x, nblk);
     const int b = v / blocks_per_image, chunk = v - b * blocks_per_image;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     Theta th;
 #pragma unroll
     for (int j = 0; j < 9; ++j) th.a[j] = theta[(size_t)b * 9 + j];
-    const float* __restrict__ Ub = U + (size_t)b * H * W * C;
-    const float sx = lin_step(W), sy = lin_step(H);
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(U + (size_t)b * H * W * C, (unsigned)(H * W * C * 4));
+    const SrcGeom g = make_geom<C>(W, H);
     const float halfW = (float)W * 0.5f, halfH = (float)H * 0.5f;
     float acc[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
+    constexpr int BT = 2;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int i = chunk * PB + k * 256 + threadIdx.x;
-        if (i >= PP) break;
-        const size_t e = (size_t)b * PP + i;
-        const int idx = patch_idx[e];
-        const int row = idx / W, col = idx - row * W;
-        const float gx = lin_at(sx, col), gy = lin_at(sy, row);
-        const Sample s = make_sample(th, gx, gy, W, H);
-        const int ra = s.y0 * W, rb = s.y1 * W;
-        const float* pa = Ub + (ra + s.x0) * C; const float* pb = Ub + (rb + s.x0) * C;
-        const float* pc = Ub + (ra + s.x1) * C; const float* pd = Ub + (rb + s.x1) * C;
-        float Ia[C], Ib[C], Ic[C], Id[C];
+    for (int k0 = 0; k0 < PPT; k0 += BT) {
+        Tap s[BT];
+        Pix<C> Ia[BT], Ib[BT], Ic[BT], Id[BT];
+        float gx[BT], gy[BT], tgt[BT];
+        bool ok[BT];
+        size_t e[BT];
 #pragma unroll
-        for (int c = 0; c < C; ++c) { Ia[c] = pa[c]; Ib[c] = pb[c]; Ic[c] = pc[c]; Id[c] = pd[c]; }
-        float gsum = blend(s, Ia[0], Ib[0], Ic[0], Id[0]);
+        for (int k = 0; k < BT; ++k) {
+            const int i = chunk * PB + (k0 + k) * 256 + (int)threadIdx.x;
+            ok[k] = i < PP;
+            e[k] = (size_t)b * PP + (ok[k] ? i : PP - 1);
+            const int idx = patch_idx[e[k]];
+            tgt[k] = I2[e[k]];
+            int row, col;
+            split_index<SMALL>(idx, W, invW, row, col);
+            gx[k] = lin_at(sx, col); gy[k] = lin_at(sy, row);
+            s[k] = make_tap<C, SMALL>(th, th.a[0] * gx[k], th.a[3] * gx[k], th.a[6] * gx[k], gy[k], g);
+            Ia[k] = buf_load<C>(rin, s[k].oa, 0);
+            Ib[k] = buf_load<C>(rin, s[k].ob, 0);
+            Ic[k] = buf_load<C>(rin, s[k].oc, 0);
+            Id[k] = buf_load<C>(rin, s[k].od, 0);
+        }
 #pragma unroll
-        for (int c = 1; c < C; ++c) gsum = gsum + blend(s, Ia[c], Ib[c], Ic[c], Id[c]);
-        const float p = gsum / (float)C;
-        pred[e] = p;
-        const float d = p - I2[e];
-        acc[9] += fabsf(d);
-        if (WANT_GRAD) {
-            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            float ex = 0.f, ey = 0.f;
+        for (int k = 0; k < BT; ++k) {
+            const float wa = s[k].ax1 * s[k].ay1, wb = s[k].ax1 * s[k].ay0;
+            const float wc = s[k].ax0 * s[k].ay1, wd = s[k].ax0 * s[k].ay0;
+            float gsum = blend4(wa, wb, wc, wd, Ia[k].v[0], Ib[k].v[0], Ic[k].v[0], Id[k].v[0]);
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                ex += fmaf(s.ay1, Ic[c] - Ia[c], s.ay0 * (Id[c] - Ib[c]));
-                ey += fmaf(s.ax1, Ib[c] - Ia[c], s.ax0 * (Id[c] - Ic[c]));
+            for (int c = 1; c < C; ++c)
+                gsum = gsum + blend4(wa, wb, wc, wd, Ia[k].v[c], Ib[k].v[c], Ic[k].v[c], Id[k].v[c]);
+            const float p = gsum / (float)C;
+            if (ok[k]) pred[e[k]] = p;
+            const float m = ok[k] ? 1.f : 0.f;
+            const float d = p - tgt[k];
+            acc[9] += m * fabsf(d);
+            if (WANT_GRAD) {
+                const float sgn = d > 0.f ? m : (d < 0.f ? -m : 0.f);
+                float ex = 0.f, ey = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    ex += fmaf(s[k].ay1, Ic[k].v[c] - Ia[k].v[c], s[k].ay0 * (Id[k].v[c] - Ib[k].v[c]));
+                    ey += fmaf(s[k].ax1, Ib[k].v[c] - Ia[k].v[c], s[k].ax0 * (Id[k].v[c] - Ic[k].v[c]));
+                }
+                const float gg = sgn / (float)C;
+                const float rt = s[k].rt;
+                const float dxs = gg * ex * halfW * rt, dys = gg * ey * halfH * rt;
+                const float dt = -(dxs * s[k].xs + dys * s[k].ys) * rt;
+                acc[0] = fmaf(dxs, gx[k], acc[0]); acc[1] = fmaf(dxs, gy[k], acc[1]); acc[2] += dxs;
+                acc[3] = fmaf(dys, gx[k], acc[3]); acc[4] = fmaf(dys, gy[k], acc[4]); acc[5] += dys;
+                acc[6] = fmaf(dt,  gx[k], acc[6]); acc[7] = fmaf(dt,  gy[k], acc[7]); acc[8] += dt;
             }
-            const float g = sgn / (float)C;
-            const float rt = 1.0f / s.t;
-            const float dxs = g * ex * halfW * rt, dys = g * ey * halfH * rt;
-            const float dt = -(dxs * s.xs + dys * s.ys) * rt;
-            acc[0] = fmaf(dxs, gx, acc[0]); acc[1] = fmaf(dxs, gy, acc[1]); acc[2] += dxs;
-            acc[3] = fmaf(dys, gx, acc[3]); acc[4] = fmaf(dys, gy, acc[4]); acc[5] += dys;
-            acc[6] = fmaf(dt,  gx, acc[6]); acc[7] = fmaf(dt,  gy, acc[7]); acc[8] += dt;
         }
     }
 #pragma unroll
     for (int j = 0; j < NACC; ++j) {
-        const float r = wave_sum(acc[j]);
-        if (lane == 0) red[wave][j] = r;
+        if (!WANT_GRAD && j < 9) continue;
+        const float r = row16_sum(acc[j]);
+        if ((lane & 15) == 0) red[j][wave * 4 + (lane >> 4)] = r;
     }
     __syncthreads();
     if (threadIdx.x < NACC) {
-        const int j = threadIdx.x;
-        partial[(size_t)v * NACC + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+        const float* r = red[threadIdx.x];
+        float t = 0.f;
+        if (WANT_GRAD || threadIdx.x == 9) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += r[k];
+        }
+        partial[(size_t)v * NACC + threadIdx.x] = t;
     }
 }
 
@@ -130,12 +167,13 @@ extern "C" size_t uh_warp_patch_l1_workspace_bytes(int B, int PP) {
 template <int C>
 static void launch_patch(const float* U, const float* theta, const float* I2, const int* idx, float* pred,
                          float* partial, bool grad, int H, int W, int PP, int bpi, unsigned nblk, hipStream_t s) {
-    if (grad)
-        hipLaunchKernelGGL((warp_patch_l1_kernel<C, true>), dim3(nblk), dim3(256), 0, s, U, theta, I2, idx, pred,
-                           partial, H, W, PP, bpi, nblk);
-    else
-        hipLaunchKernelGGL((warp_patch_l1_kernel<C, false>), dim3(nblk), dim3(256), 0, s, U, theta, I2, idx, pred,
-                           partial, H, W, PP, bpi, nblk);
+    const bool sm = (uint64_t)H * W * C * 4 <= (1ull << 24);
+    const float sx = lin_step(W), sy = lin_step(H), invW = 1.0f / (float)W;
+#define UH_PATCH(GRAD, SM) hipLaunchKernelGGL((warp_patch_l1_kernel<C, GRAD, SM>), dim3(nblk), dim3(256), 0, s, U, theta, \
+                                              I2, idx, pred, partial, H, W, sx, sy, invW, PP, bpi, nblk)
+    if (grad) { if (sm) UH_PATCH(true, true); else UH_PATCH(true, false); }
+    else      { if (sm) UH_PATCH(false, true); else UH_PATCH(false, false); }
+#undef UH_PATCH
 }
 
 extern "C" int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const float* I2, const int* patch_idx,
