@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
     ap.add_argument('--cpu_baseline', type=int, default=1)
+    ap.add_argument('--north_star', type=int, default=1, help='0: skip the extra warp-only measurement at batch 128')
     ap.add_argument('--cpu_sample_pairs', type=int, default=8)
     ap.add_argument('--cpu_sample_steps', type=int, default=2)
     ap.add_argument('--cpu_threads', type=int, default=32, help='host threads for the CPU leg (capped at nproc)')
@@ -202,6 +203,8 @@ def main():
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_us': kern[dom]['avg_us'],
                 'timing': 'hipEvent pairs on the launch stream inside the timed region (uh_profile_*)',
                 'kernels': kern}
+    # HBM bytes per launch of the dominant kernel from the PMC passes over THIS command (tools/gpu_traffic.sh ->
+    # profiles/traffic_r01.json; FETCH_SIZE x2 KiB + WRITE_SIZE KiB, the gfx950 correction calibrated on a device copy)
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
     if os.path.exists(traffic_file):
         try:
@@ -209,7 +212,7 @@ def main():
             key = '%s_B%d_%dx%d' % (dom, B, args.img_h, args.img_w)
             if key in tr:
                 roofline['traffic'] = tr[key]['hbm_bytes_per_launch']
-                roofline['traffic_source'] = 'profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)'
+                roofline['traffic_source'] = tr[key].get('source', 'profiles/traffic_r01.json')
         except Exception:
             pass
     out = {
@@ -225,7 +228,7 @@ def main():
                    'final_loss': round(loss_val, 6)},
         'roofline': roofline,
     }
-    if world == 1:
+    if world == 1 and args.north_star:
         out['north_star_point'] = north_star_point(device, args)
     if world == 1 and args.cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
