@@ -156,6 +156,70 @@ def test_warp_forward_identity_sampling_law(ops, dev):
     assert out[0, 0, 0, 0] == U[0, 0, 0, 0]
 
 
+@pytest.mark.parametrize('C', [1, 2, 3, 4])
+def test_warp_forward_staged_and_gather_paths(ops, dev, C):
+    """The forward kernel picks, per wavefront, between the LDS-staged rectangle and the direct gather
+    (csrc/uh_warp.hip).  Near-identity / small-rotation thetas keep a 16x16 tile's taps inside a 4 KiB rectangle
+    (staged); a strong zoom-out or a 90-degree rotation does not (gather); a frame-crossing shift mixes both and
+    exercises the clipped rectangle.  All must equal the f32 oracle bit for bit."""
+    rs = np.random.RandomState(40 + C)
+    H, W = 96, 112                                        # not multiples of the 64x16 block tile
+    U = rs.randn(6, H, W, C).astype(np.float32)
+    a = np.deg2rad(7.0)
+    theta = np.array([
+        np.eye(3),                                                        # staged, cpr <= 16
+        [[np.cos(a), -np.sin(a), 0.02], [np.sin(a), np.cos(a), -0.03], [0, 0, 1]],   # staged, rotated rectangle
+        [[3.0, 0, 0], [0, 3.0, 0], [0, 0, 1]],                            # zoom-out x3: rectangle 48x48 px -> gather
+        [[0, -1, 0], [1, 0, 0], [0, 0, 1]],                               # 90 degrees: 16 px wide tile spans 16 rows
+        [[1, 0, 0.9], [0, 1, -0.8], [0, 0, 1]],                           # mostly out of frame: clipped rectangles
+        [[1.2, 0.1, 0], [-0.1, 0.9, 0], [0.3, 0.2, 1]],                   # perspective
+    ], np.float32)
+    out, cond = ops.transformer(T(U, dev), T(theta, dev), (H, W))
+    ref, c = O.transformer(U, theta, (H, W), np.float32)
+    o = out.cpu().numpy()
+    assert np.array_equal(o, ref) or np.abs(o - ref).max() <= 1e-6
+    assert (o == ref).mean() > 0.9999
+    assert float(cond) == float(c)
+    # and the backward on the same thetas against the f64 closed form evaluated at the f32 sample positions
+    # (these "round" thetas put many samples exactly on pixel boundaries, where an f32/f64 floor() flip would
+    # change a pixel's whole contribution -- see oracle.transformer_backward's coord_dtype)
+    g = rs.randn(6, H, W, C).astype(np.float32)
+    tt = T(theta, dev).requires_grad_(True)
+    ops.transformer(T(U, dev), tt, (H, W))[0].backward(T(g, dev))
+    dth = O.transformer_backward(U, theta, g, (H, W), np.float64, coord_dtype=np.float32)
+    got = tt.grad.cpu().numpy().reshape(-1, 3, 3)
+    for k in range(6):
+        assert relerr(got[k], dth[k]) < 1e-4, k
+
+
+def test_warp_forward_large_image_offsets(ops, dev):
+    """An image of more than 2^24 bytes takes the integer-offset path (offsets no longer exact in f32)."""
+    rs = np.random.RandomState(5)
+    H, W, C = 1200, 1200, 3                                # 17.3 MB > 2^24
+    U = rs.randn(1, H, W, C).astype(np.float32)
+    theta = np.array([[[0.9, 0.05, 0.01], [-0.04, 1.1, 0.02], [0.02, -0.03, 1]]], np.float32)
+    out, _ = ops.transformer(T(U, dev), T(theta, dev), (64, 96))
+    ref, _ = O.transformer(U, theta, (64, 96), np.float32)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-6
+
+
+def test_launch_profiler_reports_kernel_durations(ops, dev):
+    from unsuperviseddeephomographyral2018_amd import _lib
+    U = T(np.random.RandomState(0).randn(8, 120, 160, 3).astype(np.float32), dev)
+    th = torch.eye(3, device=dev).reshape(1, 3, 3).repeat(8, 1, 1).requires_grad_(True)
+    _lib.profile_enable(True)
+    try:
+        for _ in range(3):
+            ops.transformer(U, th, (120, 160), with_condition=False)[0].sum().backward()
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+    finally:
+        _lib.profile_enable(False)
+    for k in ('warp_forward', 'warp_backward', 'warp_backward_finish'):
+        ms, n = prof[k]
+        assert n == 3 and 0.0 < ms / n < 5.0, (k, ms, n)
+
+
 # ---------------------------------------------------------------------------------------------- warp bwd
 def test_warp_backward_dtheta_vs_oracle(ops, dev, golden):
     g = golden('chain_small.npz')

@@ -1,6 +1,7 @@
 // uh_host.h -- host-side helpers shared by the C-ABI translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "../../include/uh_hotpath.h"
 
 namespace uh {
@@ -8,9 +9,26 @@ namespace uh {
 // Optional per-launch timing (uh_profile_enable).  Events are recorded on the SAME stream as the
 // launch they bracket, so the figure is the kernel's device-side duration plus the event overhead,
 // not host wall time.  Disabled -> zero cost beyond one branch.
+extern bool g_prof_on;
 void prof_begin(int kernel, hipStream_t s);
 void prof_end(int kernel, hipStream_t s);
-extern bool g_prof_on;
+
+// Event pair for ONE kernel launch, handed to hipExtLaunchKernelGGL: the runtime stamps them with the dispatch's
+// own begin/end timestamps, so the figure is the kernel's duration on its stream without the ~3 us that a pair
+// of hipEventRecord() calls adds around a short kernel.
+void prof_pair(int kernel, hipEvent_t* a, hipEvent_t* b);
+
+// launch `kernel`; when the profiler is on, time exactly this dispatch
+template <typename K, typename... Args>
+inline void launch_timed(int kid, K kernel, dim3 grid, dim3 block, hipStream_t s, Args... args) {
+    if (g_prof_on) {
+        hipEvent_t a, b;
+        prof_pair(kid, &a, &b);
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, s, a, b, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+    }
+}
 
 struct ProfScope {
     int k; hipStream_t s; bool on;

@@ -98,6 +98,12 @@ void prof_begin(int kernel, hipStream_t s) {
     (void)hipEventRecord(r.a, s);
     g_open.push_back(r);
 }
+void prof_pair(int kernel, hipEvent_t* a, hipEvent_t* b) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Rec r{kernel, get_event(), get_event()};
+    *a = r.a; *b = r.b;
+    g_done.push_back(r);
+}
 void prof_end(int kernel, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (size_t i = g_open.size(); i-- > 0;) {

@@ -169,8 +169,8 @@ static void launch_patch(const float* U, const float* theta, const float* I2, co
                          float* partial, bool grad, int H, int W, int PP, int bpi, unsigned nblk, hipStream_t s) {
     const bool sm = (uint64_t)H * W * C * 4 <= (1ull << 24);
     const float sx = lin_step(W), sy = lin_step(H), invW = 1.0f / (float)W;
-#define UH_PATCH(GRAD, SM) hipLaunchKernelGGL((warp_patch_l1_kernel<C, GRAD, SM>), dim3(nblk), dim3(256), 0, s, U, theta, \
-                                              I2, idx, pred, partial, H, W, sx, sy, invW, PP, bpi, nblk)
+#define UH_PATCH(GRAD, SM) launch_timed(UH_K_PATCH_FUSED, warp_patch_l1_kernel<C, GRAD, SM>, dim3(nblk), dim3(256), s, U, theta, \
+                                       I2, idx, pred, partial, H, W, sx, sy, invW, PP, bpi, nblk)
     if (grad) { if (sm) UH_PATCH(true, true); else UH_PATCH(true, false); }
     else      { if (sm) UH_PATCH(false, true); else UH_PATCH(false, false); }
 #undef UH_PATCH
@@ -191,7 +191,6 @@ extern "C" int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
     {
-        ProfScope prof(UH_K_PATCH_FUSED, s);
         const bool grad = dTheta != nullptr;
         switch (C) {
             case 1: launch_patch<1>(U, theta, I2, patch_idx, pred, partial, grad, H, W, PP, bpi, nblk, s); break;
@@ -203,9 +202,8 @@ extern "C" int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const
         if (e != hipSuccess) return (int)e;
     }
     {
-        ProfScope prof(UH_K_PATCH_FIN, s);
-        hipLaunchKernelGGL(warp_patch_l1_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, loss,
-                           dTheta, B, bpi, 1.0 / ((double)B * (double)PP));
+        launch_timed(UH_K_PATCH_FIN, warp_patch_l1_finish_kernel, dim3(1), dim3(1024), s, (const float*)partial, loss,
+                     dTheta, B, bpi, 1.0 / ((double)B * (double)PP));
     }
     return (int)hipGetLastError();
 }

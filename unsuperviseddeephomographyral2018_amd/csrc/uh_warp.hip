@@ -386,8 +386,8 @@ static void launch_fwd(const float* U, const float* theta, float* out, float* co
     const TileGeom g = tile_geom(oh, ow);
     const unsigned nblk = (unsigned)B * g.tiles;
     const bool sm = small_image(H, W, C);
-#define UH_FWD(COND, SM) hipLaunchKernelGGL((warp_forward_kernel<C, COND, SM>), dim3(nblk), dim3(256), 0, s, U, \
-                                            theta, out, condition, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk)
+#define UH_FWD(COND, SM) launch_timed(UH_K_WARP_FWD, warp_forward_kernel<C, COND, SM>, dim3(nblk), dim3(256), s, U, \
+                                     theta, out, condition, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk)
     if (condition) { if (sm) UH_FWD(true, true); else UH_FWD(true, false); }
     else           { if (sm) UH_FWD(false, true); else UH_FWD(false, false); }
 #undef UH_FWD
@@ -402,7 +402,6 @@ extern "C" int uh_warp_forward(const float* U, const float* theta, float* out, f
         hipError_t e = hipMemsetAsync(condition, 0, sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-    ProfScope prof(UH_K_WARP_FWD, s);
     switch (C) {
         case 1: launch_fwd<1>(U, theta, out, condition, B, H, W, oh, ow, s); break;
         case 2: launch_fwd<2>(U, theta, out, condition, B, H, W, oh, ow, s); break;
@@ -424,8 +423,8 @@ static void launch_bwd(const float* U, const float* theta, const float* dOut, fl
     const TileGeom g = tile_geom(oh, ow);
     const unsigned nblk = (unsigned)B * g.tiles;
     const bool sm = small_image(H, W, C);
-#define UH_BWD(DU, SM) hipLaunchKernelGGL((warp_backward_kernel<C, DU, SM>), dim3(nblk), dim3(256), 0, s, U, \
-                                          theta, dOut, partial, dU, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk)
+#define UH_BWD(DU, SM) launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, DU, SM>, dim3(nblk), dim3(256), s, U, \
+                                   theta, dOut, partial, dU, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk)
     if (dU) { if (sm) UH_BWD(true, true); else UH_BWD(true, false); }
     else    { if (sm) UH_BWD(false, true); else UH_BWD(false, false); }
 #undef UH_BWD
@@ -444,7 +443,6 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
     }
     float* partial = (float*)workspace;
     {
-        ProfScope prof(UH_K_WARP_BWD, s);
         switch (C) {
             case 1: launch_bwd<1>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
             case 2: launch_bwd<2>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
@@ -455,9 +453,9 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
         if (e != hipSuccess) return (int)e;
     }
     {
-        ProfScope prof(UH_K_WARP_BWD_FIN, s);
         const TileGeom g = tile_geom(oh, ow);
-        hipLaunchKernelGGL(warp_backward_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, s, partial, dTheta, g.tiles, B);
+        launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel, dim3((B + 3) / 4), dim3(256), s,
+                     (const float*)partial, dTheta, g.tiles, B);
     }
     return (int)hipGetLastError();
 }
