@@ -17,6 +17,8 @@
  *                                                     homography_model.py:74-76,263-269
  *   uh_l1_loss_forward / uh_l1_loss_backward
  *        <- build_losses() l1 branch                  homography_model.py:328
+ *   uh_patch_losses_forward
+ *        <- build_losses(): rec / ssim / l1 / l1_smooth / ncc / h monitors   homography_model.py:136-166,286-352
  *   uh_warp_patch_l1_fwdbwd
  *        <- the composition of the four above restricted to the P x P loss patch
  *
@@ -112,6 +114,15 @@ UH_API int uh_l1_loss_forward(const float* pred, const float* target, float* los
 UH_API int uh_l1_loss_backward(const float* pred, const float* target, const float* dLoss, float* dPred,
                         size_t n, uh_stream_t stream);
 
+/* ---- all photometric losses in one pass ---------------------------------------------
+ * pred, target [B,P,P] (one channel)  ->  out6[6] (device):
+ *   [0] rec_loss  [1] ssim_loss  [2] l1_loss  [3] l1_smooth_loss  [4] ncc_loss        homography_model.py:136-166,286-352
+ *   [5] h_loss = sqrt(mean((h4p - gt)^2)) over [B,8] when h4p/gt are given (both or neither), else 0      :288
+ * Forward values only (the stop_gradient monitors the reference fetches every step).                            */
+UH_API size_t uh_patch_losses_workspace_bytes(int B, int P);
+UH_API int uh_patch_losses_forward(const float* pred, const float* target, const float* h4p, const float* gt,
+                            float* out6, void* workspace, size_t workspace_bytes, int B, int P, uh_stream_t stream);
+
 /* ---- fused patch path ---------------------------------------------------------
  * For the P x P loss patch only: sample -> gray -> |pred - I2| -> loss, and d loss/d theta for
  * dLoss = 1, in ONE pass that never materialises the warped frame.
@@ -137,7 +148,9 @@ UH_API int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const flo
 #define UH_K_L1_BWD         8
 #define UH_K_PATCH_FUSED    9
 #define UH_K_PATCH_FIN     10
-#define UH_K_COUNT         11
+#define UH_K_LOSSES        11
+#define UH_K_LOSSES_FIN    12
+#define UH_K_COUNT         13
 UH_API int uh_profile_enable(int on);                        /* returns previous state; resets counters  */
 UH_API int uh_profile_read(double* total_ms /*[UH_K_COUNT]*/, long long* launches /*[UH_K_COUNT]*/);
 UH_API const char* uh_kernel_name(int k);

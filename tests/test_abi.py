@@ -17,7 +17,8 @@ def declared_symbols():
 def test_header_declares_expected_entry_points():
     syms = declared_symbols()
     for must in ('uh_dlt_forward', 'uh_dlt_backward', 'uh_warp_forward', 'uh_warp_backward',
-                 'uh_warp_backward_workspace_bytes', 'uh_warp_patch_l1_fwdbwd', 'uh_gray_patch_forward',
+                 'uh_warp_backward_workspace_bytes', 'uh_warp_patch_l1_fwdbwd', 'uh_patch_losses_forward',
+                 'uh_patch_losses_workspace_bytes', 'uh_gray_patch_forward',
                  'uh_l1_loss_forward'):
         assert must in syms
     assert len(syms) >= 17

@@ -279,6 +279,22 @@ def test_gray_patch_and_l1(ops, dev, golden):
     np.testing.assert_allclose(w.grad.cpu().numpy(), ref, rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize('B,P', [(3, 16), (2, 128), (5, 37)])
+def test_patch_losses_vs_oracle(ops, dev, B, P):
+    """uh_patch_losses_forward (rec / ssim / l1 / l1_smooth / ncc / h) vs the NumPy restatement of
+    homography_model.py:136-166,286-352 in f64; inputs span |d| < 1 and |d| > 1 (both smooth-L1 branches)."""
+    rs = np.random.RandomState(B * 100 + P)
+    x = (rs.randn(B, P, P, 1) * 1.5).astype(np.float32)
+    y = (x + rs.randn(B, P, P, 1) * rs.choice([0.05, 0.8, 2.0], size=(B, 1, 1, 1))).astype(np.float32)
+    h4p = rs.randn(B, 8).astype(np.float32) * 20; gt = rs.randint(-45, 46, (B, 8)).astype(np.float32)
+    got = ops.patch_losses(T(x, dev), T(y, dev), T(h4p, dev), T(gt, dev)).cpu().numpy()
+    ref = O.patch_losses(x, y, h4p, gt)
+    for i, k in enumerate(('rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss', 'h_loss')):
+        assert abs(got[i] - ref[k]) <= 1e-5 * max(1.0, abs(ref[k])), (k, got[i], ref[k])
+    got2 = ops.patch_losses(T(x, dev), T(y, dev)).cpu().numpy()
+    assert np.array_equal(got2[:5], got[:5]) and got2[5] == 0.0
+
+
 def test_gray_patch_duplicate_indices(ops, dev):
     """patch_indices with collisions: backward must accumulate (gather grad = scatter-ADD)."""
     w = torch.randn(1, 4, 4, 3, device=dev, requires_grad=True)

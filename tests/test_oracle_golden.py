@@ -127,3 +127,24 @@ def test_int32_overflow_semantics():
     assert np.isfinite(out).all()
     x = O._float_to_int32_x86(np.array([3e9, -3e9, np.nan, 5.0], np.float32))
     assert list(x) == [-2147483648, -2147483648, -2147483648, 5]
+
+
+def test_patch_losses_oracle_vs_torch_ops():
+    """The NumPy restatement of the monitor losses (homography_model.py:136-166) against an independent evaluation
+    with torch ops (avg_pool2d == slim.avg_pool2d VALID, stride 1)."""
+    import torch
+    import torch.nn.functional as F
+    rs = np.random.RandomState(11)
+    x = rs.randn(3, 24, 24, 1); y = x + 0.7 * rs.randn(3, 24, 24, 1)
+    ref = O.patch_losses(x, y, rs.randn(3, 8), rs.randn(3, 8))
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2); yt = torch.from_numpy(y).permute(0, 3, 1, 2)
+    pool = lambda v: F.avg_pool2d(v, 3, 1)
+    mx, my = pool(xt), pool(yt)
+    sx = pool(xt ** 2) - mx ** 2; sy = pool(yt ** 2) - my ** 2; sxy = pool(xt * yt) - mx * my
+    ssim = ((2 * mx * my + 1e-4) * (2 * sxy + 9e-4)) / ((mx ** 2 + my ** 2 + 1e-4) * (sx + sy + 9e-4))
+    assert abs(float(torch.clamp((1 - ssim) / 2, 0, 1).mean()) - ref['ssim_loss']) < 1e-12
+    ad = (xt - yt).abs()
+    assert abs(float(torch.where(ad < 1, 0.5 * ad * ad, ad - 0.5).mean()) - ref['l1_smooth_loss']) < 1e-12
+    assert abs(float(torch.sqrt(((xt - yt) ** 2).mean())) - ref['rec_loss']) < 1e-12
+    lx = torch.sqrt((xt ** 2).sum()); ly = torch.sqrt((yt ** 2).sum())
+    assert abs(float(torch.sqrt(((yt / ly - xt / lx) ** 2).sum())) - ref['ncc_loss']) < 1e-12

@@ -221,29 +221,28 @@ class HomographyModel(object):
                 # If it is a fail, use identity matrix
                 self.bounded_h_loss = torch.mean(batch_h_loss * (1 - is_failure) + is_failure * h_loss_identity)
 
-        def maybe_stop(active, fn):
-            if active:
-                return fn()
-            with torch.no_grad():
-                return fn()
-
         pred = self.pred_I2
-        pred_m = pred.detach()                       # monitors never carry gradient
-        self.h_loss = maybe_stop(lt == 'h_loss', lambda: torch.sqrt(torch.mean((self.pred_h4p - self.gt) ** 2)))
-        self.rec_loss = maybe_stop(lt == 'rec_loss', lambda: torch.sqrt(torch.mean(
-            ((pred if lt == 'rec_loss' else pred_m) - I2) ** 2)))
-        self.ssim_loss = maybe_stop(lt == 'ssim_loss', lambda: torch.mean(self._SSIM_loss(
-            pred if lt == 'ssim_loss' else pred_m, I2)))
-        if lt == 'l1_loss':
+        # Every loss that is NOT being trained on is a stop_gradient monitor (homography_model.py:286-352): one
+        # HIP launch yields all of them (csrc/uh_losses.hip).  The trained loss keeps a differentiable path:
+        # l1_loss through the HIP L1 kernels (or the fused patch kernel), the others through torch autograd.
+        mon = ops.patch_losses(pred, I2, self.pred_h4p, self.gt)
+        self.h_loss, self.rec_loss, self.ssim_loss = mon[5], mon[0], mon[1]
+        self.l1_loss, self.l1_smooth_loss, self.ncc_loss = mon[2], mon[3], mon[4]
+        if not torch.is_grad_enabled():
+            return
+        if lt == 'h_loss':
+            self.h_loss = torch.sqrt(torch.mean((self.pred_h4p - self.gt) ** 2))
+        elif lt == 'rec_loss':
+            self.rec_loss = torch.sqrt(torch.mean((pred - I2) ** 2))
+        elif lt == 'ssim_loss':
+            self.ssim_loss = torch.mean(self._SSIM_loss(pred, I2))
+        elif lt == 'l1_loss':
             # the photometric L1 of the hot path: HIP reduction kernel (or the fused patch kernel's output)
             self.l1_loss = self._l1_fused if self._l1_fused is not None else ops.l1_loss(pred, I2)
-        else:
-            with torch.no_grad():
-                self.l1_loss = ops.l1_loss(pred_m, I2)
-        self.l1_smooth_loss = maybe_stop(lt == 'l1_smooth_loss', lambda: self._L1_smooth_loss(
-            pred if lt == 'l1_smooth_loss' else pred_m, I2))
-        self.ncc_loss = maybe_stop(lt == 'ncc_loss', lambda: self._NCC_loss(
-            I2, pred if lt == 'ncc_loss' else pred_m))
+        elif lt == 'l1_smooth_loss':
+            self.l1_smooth_loss = self._L1_smooth_loss(pred, I2)
+        elif lt == 'ncc_loss':
+            self.ncc_loss = self._NCC_loss(I2, pred)
 
     @property
     def loss(self):

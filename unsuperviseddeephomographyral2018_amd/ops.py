@@ -230,6 +230,26 @@ def l1_loss(pred, target):
     return _L1Loss.apply(pred, target)
 
 
+def patch_losses(pred, target, h4p=None, gt=None):
+    """All photometric losses of build_losses() in one launch, forward values only (homography_model.py:136-166,
+    286-352): returns a [6] tensor (rec, ssim, l1, l1_smooth, ncc, h_loss); h_loss = 0 unless h4p and gt are given."""
+    lib = _lib.load()
+    pred = _f32(pred.detach(), 'pred'); target = _f32(target.detach(), 'target')
+    if pred.dim() != 4 or pred.shape[3] != 1 or pred.shape[1] != pred.shape[2] or target.shape != pred.shape:
+        raise _lib.UHError('patch_losses expects pred and target of shape [B,P,P,1]')
+    B, P = pred.shape[0], pred.shape[1]
+    if h4p is not None:
+        h4p = _f32(h4p.detach(), 'h4p').reshape(-1); gt = _f32(gt.detach(), 'gt').reshape(-1)
+        if h4p.numel() != B * 8 or gt.numel() != B * 8:
+            raise _lib.UHError('h4p and gt must be [B,8]')
+    out = torch.empty((6,), dtype=torch.float32, device=pred.device)
+    nbytes = lib.uh_patch_losses_workspace_bytes(B, P)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=pred.device)
+    _lib.check(lib.uh_patch_losses_forward(_ptr(pred), _ptr(target), _ptr(h4p), _ptr(gt), _ptr(out), _ptr(ws), nbytes,
+                                           B, P, _stream()), 'uh_patch_losses_forward')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 class _WarpPatchL1(torch.autograd.Function):
     """Fused patch path: (U, theta, I2, patch_idx) -> (loss, pred_I2).  The kernel produces dTheta for
