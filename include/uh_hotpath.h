@@ -17,6 +17,9 @@
  *                                                     homography_model.py:74-76,263-269
  *   uh_l1_loss_forward / uh_l1_loss_backward
  *        <- build_losses() l1 branch                  homography_model.py:328
+ *   uh_prepare_inputs
+ *        <- the per-sample graph of Dataloader.__init__ (cast, augment, standardise, gray patches, patch indices)
+ *                                                     dataloader.py:160-227,317-375
  *   uh_patch_losses_forward
  *        <- build_losses(): rec / ssim / l1 / l1_smooth / ncc / h monitors   homography_model.py:136-166,286-352
  *   uh_warp_patch_l1_fwdbwd
@@ -114,6 +117,20 @@ UH_API int uh_l1_loss_forward(const float* pred, const float* target, float* los
 UH_API int uh_l1_loss_backward(const float* pred, const float* target, const float* dLoss, float* dPred,
                         size_t n, uh_stream_t stream);
 
+/* ---- producer of the dataloader's output contract ------------------------------------
+ * Decoded uint8 frames I, I' [B,H,W,3] -> the tensors HomographyModel takes (dataloader.py:160-227, 317-375):
+ *   aug [B,2,5] (device, may be NULL = no augmentation): per image gamma, brightness, colour r,g,b; value =
+ *       clip(v^gamma * brightness * colour_c, 0, 255)                                        dataloader.py:353-375
+ *   I_aug, Iprime_aug [B,H,W,3] = (augmented - mean_c)/std_c                                  :172-177
+ *   I1, I2 [B,P,P] = channel mean of the NON-augmented standardised frames at the patch; I1_aug, I2_aug the same of
+ *       the augmented ones                                                                    :210-227
+ *   patch_idx [B,P*P] = (v + y0)*W + (u + x0), (x0, y0) = pts1[b, 0:2]                        :197-207
+ * mean3_host / std3_host: HOST pointers to 3 floats (dataloader.py:99-100).                                       */
+UH_API int uh_prepare_inputs(const unsigned char* I_u8, const unsigned char* Iprime_u8, const float* aug,
+                      const float* pts1, const float* mean3_host, const float* std3_host,
+                      float* I_aug, float* Iprime_aug, float* I1, float* I2, float* I1_aug, float* I2_aug,
+                      int* patch_idx, int B, int H, int W, int P, uh_stream_t stream);
+
 /* ---- all photometric losses in one pass ---------------------------------------------
  * pred, target [B,P,P] (one channel)  ->  out6[6] (device):
  *   [0] rec_loss  [1] ssim_loss  [2] l1_loss  [3] l1_smooth_loss  [4] ncc_loss        homography_model.py:136-166,286-352
@@ -150,7 +167,8 @@ UH_API int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const flo
 #define UH_K_PATCH_FIN     10
 #define UH_K_LOSSES        11
 #define UH_K_LOSSES_FIN    12
-#define UH_K_COUNT         13
+#define UH_K_PREPARE       13
+#define UH_K_COUNT         14
 UH_API int uh_profile_enable(int on);                        /* returns previous state; resets counters  */
 UH_API int uh_profile_read(double* total_ms /*[UH_K_COUNT]*/, long long* launches /*[UH_K_COUNT]*/);
 UH_API const char* uh_kernel_name(int k);

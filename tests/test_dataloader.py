@@ -1,0 +1,122 @@
+"""Dataloader contract: text formats, augmentation law (CPU) and the GPU producer kernel vs the oracle (gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+from oracle import hotpath_numpy as O          # noqa: E402  (checker only)
+
+
+def _frames(rs, B, H, W):
+    lo = rs.randint(0, 256, (B, H // 8 + 2, W // 8 + 2, 3)).astype(np.float32)
+    t = torch.from_numpy(lo).permute(0, 3, 1, 2)
+    up = torch.nn.functional.interpolate(t, size=(H, W), mode='bilinear', align_corners=True)
+    return up.permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8).numpy()
+
+
+def test_text_formats_roundtrip(tmp_path, uh_lib_path):
+    """np.savetxt rows / 'a b' filename lines as gen_synthetic_data.py:121-126 writes them, read back as dataloader.py:49-72."""
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    rs = np.random.RandomState(0)
+    I = _frames(rs, 3, 24, 32); Ip = _frames(rs, 3, 24, 32)
+    pts1 = np.array([[4, 5, 12, 5, 12, 13, 4, 13]] * 3, np.float32) + np.arange(3)[:, None]
+    gt = rs.randint(-3, 4, (3, 8)).astype(np.float32)
+    ff, fp, fg = dl.write_dataset(str(tmp_path), I, Ip, pts1, gt)
+    names, p1, g = dl.read_img_and_gt(ff, fp, fg)
+    assert names == [['%d.png' % i] * 2 for i in range(3)]
+    assert np.array_equal(p1, pts1) and np.array_equal(g, gt)
+    assert open(fp).readline().split()[0] == '4.000000000000000000e+00'      # np.savetxt default format
+    names2, _, g2 = dl.read_img_and_gt(ff, fp, None)
+    assert g2 is None and names2 == names
+    assert np.array_equal(dl._decode(os.path.join(str(tmp_path), 'I', '1.png'), 24, 32), I[1])
+    assert dl._decode(os.path.join(str(tmp_path), 'I', '1.png'), 12, 16).shape == (12, 16, 3)   # area resize
+
+
+def test_augmentation_law(uh_lib_path):
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    g = torch.Generator().manual_seed(1)
+    a = dl.sample_augmentation(4000, 'train', 0.5, g).numpy()
+    ident = np.all(a == 1.0, axis=(1, 2))
+    assert 0.45 < ident.mean() < 0.55                         # applied with probability do_augment
+    aug = a[~ident]
+    assert np.array_equal(aug[:, 0], aug[:, 1])               # joint in training (dataloader.py:353-375)
+    assert aug[:, 0, 0].min() >= 0.8 and aug[:, 0, 0].max() <= 1.2
+    assert aug[:, 0, 1].min() >= 0.5 and aug[:, 0, 1].max() <= 2.0 and aug[:, 0, 1].max() > 1.9
+    assert aug[:, 0, 2:].min() >= 0.8 and aug[:, 0, 2:].max() <= 1.2
+    t = dl.sample_augmentation(2000, 'test', 1.0, g).numpy()
+    assert not np.array_equal(t[:, 0], t[:, 1])               # disjoint in test mode (:323-351)
+    assert np.all(dl.sample_augmentation(16, 'train', 0.0, g).numpy() == 1.0)
+
+
+def test_oracle_prepare_inputs_identity_augmentation_is_exact():
+    rs = np.random.RandomState(3)
+    I = _frames(rs, 2, 16, 20); Ip = _frames(rs, 2, 16, 20)
+    pts1 = np.array([[2, 3] + [0] * 6, [5, 1] + [0] * 6], np.float32)
+    a = O.prepare_inputs(I, Ip, pts1, 8, None)
+    b = O.prepare_inputs(I, Ip, pts1, 8, np.ones((2, 2, 5), np.float32))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a['patch_indices'][1, 0] == 1 * 20 + 5 and a['patch_indices'][1, 9] == 2 * 20 + 6
+    g = ((I[0, 3, 2].astype(np.float32) - np.array([118.93, 113.97, 102.60], np.float32))
+         / np.array([69.85, 68.81, 72.45], np.float32)).mean()
+    assert abs(a['I1'][0, 0, 0, 0] - g) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 48, 64, 16), (2, 37, 53, 20), (2, 240, 320, 128)])
+@pytest.mark.parametrize('with_aug', [False, True])
+def test_prepare_inputs_kernel_vs_oracle(uh_lib_path, shape, with_aug):
+    """uh_prepare_inputs vs the NumPy restatement of dataloader.py:160-227,317-375.  (37x53: H*W % 4 != 0 -> scalar path.)
+    Tolerance: the un-augmented path is pure f32 arithmetic (exact up to the division's last bit, 1e-6); with
+    augmentation v**gamma goes through powf, a few ulp of values up to 255*2 -> 2e-4 after standardisation."""
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    B, H, W, P = shape
+    rs = np.random.RandomState(B + H)
+    I = _frames(rs, B, H, W); Ip = _frames(rs, B, H, W)
+    x0 = rs.randint(0, W - P + 1, B); y0 = rs.randint(0, H - P + 1, B)
+    pts1 = np.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).astype(np.float32)
+    aug = dl.sample_augmentation(B, 'test', 1.0, torch.Generator().manual_seed(5)) if with_aug else None
+    dev = torch.device('cuda:0')
+    got = dl.prepare_inputs(torch.from_numpy(I).to(dev), torch.from_numpy(Ip).to(dev), torch.from_numpy(pts1), P, aug)
+    ref = O.prepare_inputs(I, Ip, pts1, P, None if aug is None else aug.numpy())
+    tol = 2e-4 if with_aug else 1e-6
+    for k in ('I_aug', 'I_prime_aug', 'I1', 'I2', 'I1_aug', 'I2_aug'):
+        assert np.abs(got[k].cpu().numpy() - ref[k]).max() <= tol, k
+    assert np.array_equal(got['patch_indices'].cpu().numpy(), ref['patch_indices'])
+    if not with_aug:
+        assert torch.equal(got['I1'], got['I1_aug']) and torch.equal(got['I2'], got['I2_aug'])
+
+
+@pytest.mark.gpu
+def test_dataloader_end_to_end_from_disk(tmp_path, uh_lib_path):
+    """Write a tiny dataset in the reference layout, iterate it, and run one HomographyModel step on a batch."""
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    from unsuperviseddeephomographyral2018_amd.homography_model import HomographyModel, homography_model_params
+    rs = np.random.RandomState(7)
+    N, H, W, P = 8, 64, 80, 32
+    I = _frames(rs, N, H, W); Ip = _frames(rs, N, H, W)
+    x0 = rs.randint(8, W - P - 8, N); y0 = rs.randint(8, H - P - 8, N)
+    pts1 = np.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).astype(np.float32)
+    gt = rs.randint(-8, 9, (N, 8)).astype(np.float32)
+    ff, fp, fg = dl.write_dataset(str(tmp_path) + '/', I, Ip, pts1, gt)
+    prm = dl.dataloader_params(data_path=str(tmp_path) + '/', filenames_file=ff, pts1_file=fp, gt_file=fg, mode='train',
+                               batch_size=4, img_h=H, img_w=W, patch_size=P, augment_list=['normalize'], do_augment=0.0)
+    loader = dl.Dataloader(prm, shuffle=False)
+    batches = list(loader)
+    assert len(batches) == 2 == len(loader)
+    b0 = batches[0]
+    ref = O.prepare_inputs(I[:4], Ip[:4], pts1[:4], P, None)
+    assert np.abs(b0['I_aug'].cpu().numpy() - ref['I_aug']).max() <= 1e-6
+    assert np.array_equal(b0['patch_indices'].cpu().numpy(), ref['patch_indices'])
+    assert np.array_equal(b0['gt'].cpu().numpy(), gt[:4])
+    mp = homography_model_params(mode='train', batch_size=4, patch_size=P, img_w=W, img_h=H, loss_type='l1_loss',
+                                 use_batch_norm=False, augment_list=['normalize'], leftright_consistent_weight=0)
+    m = HomographyModel(mp, b0['I1'], b0['I2'], b0['I1_aug'], b0['I2_aug'], b0['I_aug'], b0['I_prime_aug'], b0['pts1'],
+                        b0['gt'], b0['patch_indices'])
+    m.l1_loss.backward()
+    assert torch.isfinite(m.l1_loss)

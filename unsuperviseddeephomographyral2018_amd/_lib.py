@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hot
 UH_ABI_VERSION = 1
 UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
-KERNEL_COUNT = 13
+KERNEL_COUNT = 14
 
 _p = C.c_void_p
 _i = C.c_int
@@ -31,6 +31,7 @@ SIGNATURES = {
     'uh_l1_loss_workspace_bytes': (_z, [_z]),
     'uh_l1_loss_forward': (_i, [_p, _p, _p, _p, _z, _z, _p]),
     'uh_l1_loss_backward': (_i, [_p, _p, _p, _p, _z, _p]),
+    'uh_prepare_inputs': (_i, [_p] * 13 + [_i, _i, _i, _i, _p]),
     'uh_patch_losses_workspace_bytes': (_z, [_i, _i]),
     'uh_patch_losses_forward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     'uh_warp_patch_l1_workspace_bytes': (_z, [_i, _i]),

@@ -1,0 +1,171 @@
+"""Dataloader -- host-side mirror of /root/reference/code/dataloader.py for the reference's ON-DISK format.
+
+The reference's loader is a TF1 queue-runner graph: read `filenames_file` / `pts1_file` / `gt_file`
+(dataloader.py:49-72), decode `I/<name>` and `I_prime/<name>` (JPEG/PNG, :236-246), augment, standardise, gray
+patches, patch indices (:160-227), `shuffle_batch` with 20 threads (:230-235).  Here the per-sample arithmetic is
+ONE HIP kernel over a batch of decoded uint8 frames in HBM (csrc/uh_inputs.hip, `uh_prepare_inputs`); the host only
+parses the text files, decodes images (PIL, a thread pool -- JPEG entropy decoding stays on the CPU) and draws the
+augmentation parameters.  Same namedtuple, same text formats (np.savetxt rows, "a.jpg b.jpg" lines:
+utils/gen_synthetic_data.py:121-126), same output contract: the 9 tensors HomographyModel takes, NHWC f32.
+
+Differences, stated: shuffling is a seeded permutation per epoch instead of TF's min_after_dequeue window;
+`per_image_normalize` is not implemented (the reference's own branch references undefined names, :180-187);
+frames whose decoded size differs from (img_h, img_w) are area-resized with PIL's BOX filter (TF's AREA resize).
+"""
+import ctypes as C
+import os
+from collections import namedtuple
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# dataloader.py:11-22
+dataloader_params = namedtuple('parameters',
+                               'data_path,'
+                               'filenames_file,'
+                               'pts1_file,'
+                               'gt_file,'
+                               'mode,'
+                               'batch_size,'
+                               'img_h,'
+                               'img_w,'
+                               'patch_size,'
+                               'augment_list,'
+                               'do_augment,')
+
+MEAN_I = (118.93, 113.97, 102.60)          # dataloader.py:99
+STD_I = (69.85, 68.81, 72.45)              # dataloader.py:100
+
+
+def read_img_and_gt(filenames_file, pts1_file, gt_file):
+    """dataloader.py:49-72 -> (list of [nameA, nameB], pts1 [N,8] f64, gt [N,8] f64 or None)."""
+    with open(pts1_file) as f:
+        pts1 = np.array([l.split() for l in (x.strip() for x in f) if l]).astype('float64')
+    with open(filenames_file) as f:
+        names = [l.split() for l in (x.strip() for x in f) if l]
+    if not gt_file:
+        return names, pts1, None
+    with open(gt_file) as f:
+        gt = np.array([l.split() for l in (x.strip() for x in f) if l]).astype('float64')
+    return names, pts1, gt
+
+
+def sample_augmentation(B, mode, do_augment, generator=None):
+    """Augmentation parameters [B,2,5] (gamma, brightness, colour r,g,b for I and I') on the CPU.
+
+    Law of dataloader.py:160-166,323-375: with probability `do_augment` a pair is augmented -- gamma ~ U(0.8,1.2),
+    brightness ~ U(0.5,2.0), colour ~ U(0.8,1.2)^3 -- JOINTLY (same draw for both images) in training, DISJOINTLY in
+    test mode; otherwise the identity (1,1,1,1,1), which the kernel maps to the un-augmented values exactly."""
+    g = generator
+    u = lambda lo, hi, *shape: lo + (hi - lo) * torch.rand(*shape, generator=g)
+    p = torch.cat([u(0.8, 1.2, B, 2, 1), u(0.5, 2.0, B, 2, 1), u(0.8, 1.2, B, 2, 3)], 2)
+    if mode == 'train':
+        p[:, 1] = p[:, 0]
+    apply = torch.rand(B, generator=g) > (1.0 - do_augment)
+    ident = torch.ones(B, 2, 5)
+    return torch.where(apply[:, None, None], p, ident).contiguous()
+
+
+def prepare_inputs(I_u8, I_prime_u8, pts1, patch_size, aug=None, mean=MEAN_I, std=STD_I):
+    """uint8 frames [B,H,W,3] (on the HIP device) -> dict of the model's input tensors via uh_prepare_inputs."""
+    lib = _lib.load()
+    for t, n in ((I_u8, 'I_u8'), (I_prime_u8, 'I_prime_u8')):
+        if not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 4 or t.shape[3] != 3:
+            raise _lib.UHError('%s must be a uint8 [B,H,W,3] tensor on the HIP device' % n)
+    I_u8 = I_u8.contiguous(); I_prime_u8 = I_prime_u8.contiguous()
+    B, H, W, _ = I_u8.shape
+    P = int(patch_size)
+    dev = I_u8.device
+    pts1 = pts1.to(device=dev, dtype=torch.float32).contiguous()
+    if aug is not None:
+        aug = aug.to(device=dev, dtype=torch.float32).contiguous()
+        if tuple(aug.shape) != (B, 2, 5):
+            raise _lib.UHError('aug must be [B,2,5]')
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    out = dict(I_aug=f(B, H, W, 3), I_prime_aug=f(B, H, W, 3), I1=f(B, P, P, 1), I2=f(B, P, P, 1),
+               I1_aug=f(B, P, P, 1), I2_aug=f(B, P, P, 1),
+               patch_indices=torch.empty((B, P * P), dtype=torch.int32, device=dev), pts1=pts1)
+    m = (C.c_float * 3)(*mean); s = (C.c_float * 3)(*std)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(lib.uh_prepare_inputs(p(I_u8), p(I_prime_u8), p(aug), p(pts1), m, s, p(out['I_aug']), p(out['I_prime_aug']),
+                                     p(out['I1']), p(out['I2']), p(out['I1_aug']), p(out['I2_aug']),
+                                     p(out['patch_indices']), B, H, W, P,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'uh_prepare_inputs')
+    return out
+
+
+def _decode(path, img_h, img_w):
+    from PIL import Image
+    with Image.open(path) as im:
+        im = im.convert('RGB')
+        if im.size != (img_w, img_h):
+            im = im.resize((img_w, img_h), Image.BOX)
+        return np.asarray(im, dtype=np.uint8)
+
+
+class Dataloader(object):
+    """Iterate batches of a dataset stored in the reference's format:
+        <data_path>/I/<name>, <data_path>/I_prime/<name>, filenames_file ("a.jpg b.jpg" per line; the second token
+        names both files, dataloader.py:148-149), pts1_file, gt_file (one np.savetxt row of 8 floats per pair)."""
+
+    def __init__(self, params, shuffle=True, device='cuda', seed=0, num_threads=20):
+        self.params = params
+        self.shuffle = shuffle
+        self.device = torch.device(device)
+        self.names, self.pts1, self.gt = read_img_and_gt(params.filenames_file, params.pts1_file, params.gt_file)
+        if len(self.names) != len(self.pts1) or (self.gt is not None and len(self.gt) != len(self.names)):
+            raise ValueError('filenames / pts1 / gt files disagree on the number of pairs')
+        self.gen = torch.Generator().manual_seed(seed)
+        self.pool = ThreadPoolExecutor(max_workers=num_threads)
+        if 'per_image_normalize' in params.augment_list:
+            raise NotImplementedError('per_image_normalize (the reference branch itself is broken, dataloader.py:180-187)')
+
+    def __len__(self):
+        return len(self.names) // self.params.batch_size
+
+    def _load(self, i):
+        pr = self.params
+        name = self.names[i][1] if len(self.names[i]) > 1 else self.names[i][0]
+        return (_decode(os.path.join(pr.data_path, 'I', name), pr.img_h, pr.img_w),
+                _decode(os.path.join(pr.data_path, 'I_prime', name), pr.img_h, pr.img_w))
+
+    def __iter__(self):
+        pr = self.params
+        n = len(self.names)
+        order = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
+        for s in range(0, n - pr.batch_size + 1, pr.batch_size):
+            ids = order[s:s + pr.batch_size]
+            frames = list(self.pool.map(self._load, ids))
+            I8 = torch.from_numpy(np.stack([f[0] for f in frames])).to(self.device, non_blocking=True)
+            Ip8 = torch.from_numpy(np.stack([f[1] for f in frames])).to(self.device, non_blocking=True)
+            pts1 = torch.from_numpy(self.pts1[ids].astype(np.float32))
+            aug = sample_augmentation(len(ids), pr.mode, pr.do_augment, self.gen) if pr.do_augment > 0 else None
+            normalize = 'normalize' in pr.augment_list
+            batch = prepare_inputs(I8, Ip8, pts1, pr.patch_size, aug,
+                                   MEAN_I if normalize else (0., 0., 0.), STD_I if normalize else (1., 1., 1.))
+            batch['gt'] = (torch.from_numpy(self.gt[ids].astype(np.float32)).to(self.device)
+                           if self.gt is not None else torch.zeros(len(ids), 8, device=self.device))
+            yield batch
+
+
+def write_dataset(data_path, I_u8, I_prime_u8, pts1, gt, prefix='', fmt='png'):
+    """Write pairs in the reference's on-disk layout (utils/gen_synthetic_data.py:100-126): I/<i>.<fmt>,
+    I_prime/<i>.<fmt>, <prefix>filenames.txt, <prefix>pts1.txt, <prefix>gt.txt.  Returns the three text paths."""
+    from PIL import Image
+    os.makedirs(os.path.join(data_path, 'I'), exist_ok=True)
+    os.makedirs(os.path.join(data_path, 'I_prime'), exist_ok=True)
+    ff = os.path.join(data_path, prefix + 'filenames.txt')
+    fp = os.path.join(data_path, prefix + 'pts1.txt')
+    fg = os.path.join(data_path, prefix + 'gt.txt')
+    with open(ff, 'w') as f_names, open(fp, 'w') as f_pts1, open(fg, 'w') as f_gt:
+        for i in range(len(I_u8)):
+            name = '%d.%s' % (i, fmt)
+            Image.fromarray(np.asarray(I_u8[i], np.uint8)).save(os.path.join(data_path, 'I', name))
+            Image.fromarray(np.asarray(I_prime_u8[i], np.uint8)).save(os.path.join(data_path, 'I_prime', name))
+            np.savetxt(f_gt, [np.asarray(gt[i], np.float32)], delimiter=' ')
+            np.savetxt(f_pts1, [np.asarray(pts1[i], np.float32)], delimiter=' ')
+            f_names.write('%s %s\n' % (name, name))
+    return ff, fp, fg

@@ -19,6 +19,7 @@ import time
 import numpy as np
 import torch
 
+from . import dataloader as uh_data
 from . import dist as uh_dist
 from . import synthetic
 from .homography_model import HomographyModel, VGGRegressor, homography_model_params
@@ -50,6 +51,14 @@ def build_parser():
     p.add_argument('--results_dir', type=str, default='../results/synthetic/report/')
     p.add_argument('--model_dir', type=str, default='../models/synthetic_models')
     p.add_argument('--model_name', type=str, default='model.ckpt')
+    # dataset in the reference's on-disk layout (:62-70); empty data_path -> in-HBM synthetic pairs (synthetic.py)
+    p.add_argument('--data_path', type=str, default='', help='The raw data path (I/, I_prime/ under it)')
+    p.add_argument('--pts1_file', type=str, default='', help='4 corners on the first image - training dataset')
+    p.add_argument('--test_pts1_file', type=str, default='')
+    p.add_argument('--gt_file', type=str, default='', help='The training ground truth file')
+    p.add_argument('--test_gt_file', type=str, default='')
+    p.add_argument('--filenames_file', type=str, default='', help='File that contains all names of files, for training')
+    p.add_argument('--test_filenames_file', type=str, default='')
     p.add_argument('--img_w', type=int, default=WIDTH)
     p.add_argument('--img_h', type=int, default=HEIGHT)
     p.add_argument('--patch_size', type=int, default=PATCH_SIZE)
@@ -159,9 +168,25 @@ def train(args):
     names = ['h_loss', 'rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss']
     totals = torch.zeros(len(names), device=device)
     batch = None
+    disk = None
+    if args.data_path:
+        # the reference's Dataloader (:186) on its on-disk format; every rank reads its own shuffled stream
+        prm = uh_data.dataloader_params(data_path=args.data_path, filenames_file=args.filenames_file,
+                                        pts1_file=args.pts1_file, gt_file=args.gt_file, mode='train', batch_size=B_local,
+                                        img_h=args.img_h, img_w=args.img_w, patch_size=args.patch_size,
+                                        augment_list=args.augment_list, do_augment=args.do_augment)
+        loader = uh_data.Dataloader(prm, shuffle=True, device=device, seed=args.seed * 1000 + rank)
+
+        def forever():
+            while True:
+                for b in loader:
+                    yield b
+        disk = forever()
     t0 = time.time()
     for step in range(start_step, start_step + args.num_total_steps):
-        if batch is None or (step - start_step) % max(args.fresh_data_every, 1) == 0:
+        if disk is not None:
+            batch = next(disk)
+        elif batch is None or (step - start_step) % max(args.fresh_data_every, 1) == 0:
             # every rank draws its own shard (seeded by step and rank) == tf.split of a global batch
             batch = synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
                                          seed=args.seed + step * world + rank, device=device)
@@ -206,14 +231,31 @@ class TestHomography(object):
 
     def run(self):
         a = self.args
-        steps_per_epoch = int(np.ceil(a.num_test_data / a.batch_size))
+        disk = None
+        num_test_data = a.num_test_data
+        if getattr(a, 'data_path', '') and getattr(a, 'test_filenames_file', ''):
+            # the reference's test Dataloader (:138-148, :441): disjoint augmentation, no shuffling
+            prm = uh_data.dataloader_params(data_path=a.data_path, filenames_file=a.test_filenames_file,
+                                            pts1_file=a.test_pts1_file, gt_file=a.test_gt_file, mode='test',
+                                            batch_size=a.batch_size, img_h=a.img_h, img_w=a.img_w,
+                                            patch_size=a.patch_size, augment_list=a.augment_list, do_augment=a.do_augment)
+            loader = uh_data.Dataloader(prm, shuffle=False, device=self.device, seed=a.seed)
+            num_test_data = len(loader.names)
+
+            def forever():
+                while True:
+                    for b in loader:
+                        yield b
+            disk = forever()
+        steps_per_epoch = int(np.ceil(num_test_data / a.batch_size))
         num_steps = 3 * steps_per_epoch                                   # (:400-401)
         per_pair, total_fail, total_bounded = [], 0.0, 0.0
         was_training = self.net.training
         with torch.no_grad():
             for step in range(num_steps):
-                batch = synthetic.make_batch(a.batch_size, a.img_h, a.img_w, a.patch_size, a.rho,
-                                             seed=10_000_000 + a.seed + step, device=self.device)
+                batch = next(disk) if disk is not None else synthetic.make_batch(
+                    a.batch_size, a.img_h, a.img_w, a.patch_size, a.rho, seed=10_000_000 + a.seed + step,
+                    device=self.device)
                 m = HomographyModel(self.params, *synthetic.model_args(batch), reuse_variables=True, net=self.net,
                                     solve_f64=a.solve_f64)
                 total_bounded += float(m.bounded_h_loss)
