@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--rho', type=int, default=45)
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
+    ap.add_argument('--graph_tail', type=int, default=0, help='1: DLT->warp->loss and backward as one hipGraph launch')
     ap.add_argument('--cpu_baseline', type=int, default=1)
     ap.add_argument('--north_star', type=int, default=1, help='0: skip the extra warp-only measurement at batch 128')
     ap.add_argument('--cpu_sample_pairs', type=int, default=8)
@@ -147,7 +148,8 @@ def main():
     targs = build_parser().parse_args([
         '--mode', 'train', '--loss_type', args.loss_type, '--batch_size', str(B * world),
         '--img_h', str(args.img_h), '--img_w', str(args.img_w), '--patch_size', str(args.patch_size),
-        '--rho', str(args.rho), '--fused_patch', 'True' if args.fused_patch else 'False'])
+        '--rho', str(args.rho), '--fused_patch', 'True' if args.fused_patch else 'False',
+        '--graph_tail', 'True' if args.graph_tail else 'False'])
     step_fn = TrainStep(targs, device, world)
     # synthetic pairs, generated once, resident in HBM before the timed region; each rank its own shard
     batch = synthetic.make_batch(B, args.img_h, args.img_w, args.patch_size, args.rho, seed=100 + rank,

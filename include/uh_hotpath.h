@@ -22,6 +22,8 @@
  *                                                     dataloader.py:160-227,317-375
  *   uh_patch_losses_forward
  *        <- build_losses(): rec / ssim / l1 / l1_smooth / ncc / h monitors   homography_model.py:136-166,286-352
+ *   uh_tail_create / uh_tail_run
+ *        <- solve_DLT + transform + l1 loss and their backward as one hipGraph
  *   uh_warp_patch_l1_fwdbwd
  *        <- the composition of the four above restricted to the P x P loss patch
  *
@@ -150,6 +152,28 @@ UH_API int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const flo
                             const int* patch_idx, float* pred, float* loss, float* dTheta,
                             void* workspace, size_t workspace_bytes,
                             int B, int H, int W, int C, int PP, uh_stream_t stream);
+
+/* ---- the whole l1_loss tail as one call / one hipGraph launch --------------------------
+ * h4p -> DLT -> theta -> warp -> gray patch -> L1, and d L1/d h4p for dLoss = 1 (the caller scales it): solve_DLT +
+ * transform + the l1 branch of build_losses and their backward             homography_model.py:169-269,321-330
+ * A plan fixes the shapes and owns the graph cache (one captured hipGraph per distinct set of pointers + stream,
+ * LRU of 8); intermediates (theta, dtheta, warped, dWarped, dPred, reduction partials) live in the caller's workspace.
+ * uh_tail_run is serialised per plan; do not enqueue other work on `stream` from another thread during the call
+ * (the first call with a new argument set stream-captures).  With UH_TAIL_GRAPH unset, or while the launch profiler
+ * is on, or on the NULL stream, the kernels are enqueued directly.
+ *   pts1, h4p [B,8]; U [B,H,W,C]; I2 [B,P*P]; patch_idx [B,P*P]  ->  H [B,9], pred [B,P*P], loss[1], dh4p [B,8]
+ *   dh4p may be NULL (forward only).  M_host / Minv_host: HOST 3x3 constants as in uh_dlt_forward.                 */
+#define UH_TAIL_FUSED_PATCH  2u   /* use uh_warp_patch_l1_fwdbwd instead of the full-frame warp (no `warped`)      */
+#define UH_TAIL_GRAPH        4u   /* replay a captured hipGraph                                                     */
+typedef struct uh_tail_plan uh_tail_plan;
+UH_API int    uh_tail_create(uh_tail_plan** plan, int B, int H, int W, int C, int P, unsigned flags /* | UH_DLT_SOLVE_F64 */);
+UH_API size_t uh_tail_workspace_bytes(const uh_tail_plan* plan);
+UH_API size_t uh_tail_warped_offset(const uh_tail_plan* plan);   /* byte offset of `warped` [B,H,W,C] in the workspace; (size_t)-1 when fused */
+UH_API int    uh_tail_run(uh_tail_plan* plan, const float* pts1, const float* h4p, const float* U, const float* I2,
+                   const int* patch_idx, const float* M_host, const float* Minv_host, float* H, float* pred,
+                   float* loss, float* dh4p, void* workspace, size_t workspace_bytes, uh_stream_t stream);
+UH_API int    uh_tail_stats(const uh_tail_plan* plan, long long* launches, long long* captures);
+UH_API void   uh_tail_destroy(uh_tail_plan* plan);
 
 /* ---- in-library kernel timing (used by bench.py for the roofline figure) -----------------------------
  * When enabled, every launch above is bracketed by hipEventRecord on ITS stream; uh_profile_read()

@@ -146,3 +146,53 @@ def test_supervised_mode_and_test_statistics(pkg, dev):
     assert float(m.h_loss.detach()) < first
     res = drv.TestHomography(args, step_fn=step).run()
     assert res['num_pairs'] == 3 * 2 * 8 and 0 <= res['fail_percent'] <= 100 and res['mean_corner_error'] > 0
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_graph_tail_equals_unfused_chain(pkg, dev, fused):
+    """--graph_tail: DLT -> warp -> gather -> L1 and their backward as ONE library call replaying a captured hipGraph
+    (csrc/uh_tail.hip).  Same kernels, same order => identical loss / pred_I2 / H and identical parameter gradients; on
+    a non-default stream the chain is captured once and replayed afterwards."""
+    hm, synthetic, _ = pkg
+    from unsuperviseddeephomographyral2018_amd import ops
+    batch = synthetic.make_batch(B, H, W, P, RHO, seed=11, device=dev)
+    ops.TailPlan._cache.clear()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    # the model-level switch: one full step through HomographyModel(graph_tail=True) on a private stream
+    torch.manual_seed(3)
+    net = hm.VGGRegressor(P).to(dev).to(memory_format=torch.channels_last)
+    with torch.cuda.stream(side):
+        m = hm.HomographyModel(params(hm, 'train', B, P, W, H, 'l1_loss'), *synthetic.model_args(batch), net=net,
+                               fused_patch=fused, graph_tail=True)
+        m.l1_loss.backward()
+    side.synchronize()
+    assert np.isfinite(float(m.l1_loss.detach())) and all(torch.isfinite(p.grad).all() for p in net.parameters())
+    assert m.pred_I2.shape == (B, P, P, 1) and m.H_mat.shape == (B, 3, 3)
+    # the tail against the separate ops on IDENTICAL h4p (dropout makes two model constructions differ)
+    h4p = torch.randn(B, 8, device=dev) * 3
+    with torch.cuda.stream(side):
+        a = h4p.clone().requires_grad_(True)
+        Hm, th = ops.solve_dlt(batch['pts1'], a, W, H)
+        if fused:
+            la, pa = ops.warp_patch_l1(batch['I_aug'], th, batch['I2_aug'], batch['patch_indices'], P)
+        else:
+            wa, _ = ops.transformer(batch['I_aug'], th, (H, W), with_condition=False)
+            pa = ops.gray_patch_gather(wa, batch['patch_indices'], P)
+            la = ops.l1_loss(pa, batch['I2_aug'])
+        la.backward()
+        bgrad = []
+        for _ in range(3):
+            b = h4p.clone().requires_grad_(True)
+            lb, pb, Hb, plan = ops.photometric_tail(batch['pts1'], b, batch['I_aug'], batch['I2_aug'],
+                                                    batch['patch_indices'], P, fused_patch=fused, graph=True)
+            (2.0 * lb).backward()
+            bgrad.append(b.grad.clone())
+    side.synchronize()
+    assert float(la) == float(lb)
+    assert torch.equal(pa, pb) and torch.equal(Hm, Hb)
+    assert torch.equal(2.0 * a.grad, bgrad[0]) and torch.equal(bgrad[0], bgrad[2])
+    if not fused:
+        assert torch.equal(plan.warped, wa)
+    st = plan.stats()
+    assert st['captures'] >= 1 and st['launches'] >= 3 and st['captures'] <= st['launches'] - 2, st

@@ -10,6 +10,8 @@ LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hot
 UH_ABI_VERSION = 1
 UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
+UH_TAIL_FUSED_PATCH = 2
+UH_TAIL_GRAPH = 4
 KERNEL_COUNT = 14
 
 _p = C.c_void_p
@@ -36,6 +38,12 @@ SIGNATURES = {
     'uh_patch_losses_forward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     'uh_warp_patch_l1_workspace_bytes': (_z, [_i, _i]),
     'uh_warp_patch_l1_fwdbwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
+    'uh_tail_create': (_i, [_p, _i, _i, _i, _i, _i, _u]),
+    'uh_tail_workspace_bytes': (_z, [_p]),
+    'uh_tail_warped_offset': (_z, [_p]),
+    'uh_tail_run': (_i, [_p] * 12 + [_p, _z, _p]),
+    'uh_tail_stats': (_i, [_p, _p, _p]),
+    'uh_tail_destroy': (None, [_p]),
     'uh_profile_enable': (_i, [_i]),
     'uh_profile_read': (_i, [_p, _p]),
     'uh_kernel_name': (C.c_char_p, [_i]),

@@ -1,0 +1,152 @@
+// uh_tail.hip -- the whole post-regressor tail of one l1_loss training step as ONE call and ONE hipGraph launch
+// (SURVEY section 8 f2):
+//   h4p -> Tensor-DLT -> theta -> warp -> gray patch -> L1      and      d L1 / d h4p   (for dLoss = 1)
+// i.e. solve_DLT + transform + the l1 branch of build_losses and TF's backward of them
+// (/root/reference/code/homography_model.py:169-269, 321-330).  Because the loss is a scalar and the chain is
+// evaluated at dLoss = 1, the backward does not have to wait for autograd: the caller scales dh4p by the incoming
+// gradient.  The 9 kernels + 1 memset of the un-fused chain (4 kernels with the fused patch kernel) are stream-captured
+// once per distinct argument set and replayed with hipGraphLaunch: one host call and one launch per step instead
+// of ten ctypes round trips, and no inter-kernel launch gaps on the stream.
+#include "uh_device.h"
+#include "uh_host.h"
+#include <mutex>
+#include <vector>
+#include <cstring>
+
+struct uh_tail_plan {
+    int B, H, W, C, P;
+    unsigned flags;
+    // workspace layout (byte offsets, 256-byte aligned)
+    size_t off_theta, off_dtheta, off_warped, off_dwarped, off_dpred, off_ws_warp, off_ws_l1, off_ws_patch, off_one, total;
+    struct Entry { const void* key[12]; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; };
+    std::vector<Entry> cache;
+    unsigned long long clock = 0;
+    long long launches = 0, captures = 0;
+    std::mutex mu;
+};
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int uh_tail_create(uh_tail_plan** out, int B, int H, int W, int C, int P, unsigned flags) {
+    if (!out) return UH_E_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || P <= 0 || P > H || P > W) return UH_E_SHAPE;
+    if (C < 1 || C > 4) return UH_E_CHANNELS;
+    if (uh_warp_backward_workspace_bytes(B, H, W, C, H, W) == 0) return UH_E_TOO_LARGE;
+    uh_tail_plan* p = new uh_tail_plan();
+    p->B = B; p->H = H; p->W = W; p->C = C; p->P = P; p->flags = flags;
+    const bool fused = flags & UH_TAIL_FUSED_PATCH;
+    const size_t frame = (size_t)B * H * W * C * sizeof(float), patch = (size_t)B * P * P * sizeof(float);
+    size_t o = 0;
+    p->off_theta = o;   o = align256(o + (size_t)B * 9 * sizeof(float));
+    p->off_dtheta = o;  o = align256(o + (size_t)B * 9 * sizeof(float));
+    p->off_one = o;     o = align256(o + sizeof(float));
+    p->off_warped = o;  o = align256(o + (fused ? 0 : frame));
+    p->off_dwarped = o; o = align256(o + (fused ? 0 : frame));
+    p->off_dpred = o;   o = align256(o + (fused ? 0 : patch));
+    p->off_ws_warp = o; o = align256(o + (fused ? 0 : uh_warp_backward_workspace_bytes(B, H, W, C, H, W)));
+    p->off_ws_l1 = o;   o = align256(o + (fused ? 0 : uh_l1_loss_workspace_bytes((size_t)B * P * P)));
+    p->off_ws_patch = o; o = align256(o + (fused ? uh_warp_patch_l1_workspace_bytes(B, P * P) : 0));
+    p->total = o;
+    *out = p;
+    return 0;
+}
+
+extern "C" size_t uh_tail_workspace_bytes(const uh_tail_plan* p) { return p ? p->total : 0; }
+
+extern "C" size_t uh_tail_warped_offset(const uh_tail_plan* p) {
+    return (p && !(p->flags & UH_TAIL_FUSED_PATCH)) ? p->off_warped : (size_t)-1;
+}
+
+extern "C" void uh_tail_destroy(uh_tail_plan* p) {
+    if (!p) return;
+    for (auto& e : p->cache) { (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph); }
+    delete p;
+}
+
+extern "C" int uh_tail_stats(const uh_tail_plan* p, long long* launches, long long* captures) {
+    if (!p) return UH_E_NULL;
+    if (launches) *launches = p->launches;
+    if (captures) *captures = p->captures;
+    return 0;
+}
+
+static int enqueue_chain(const uh_tail_plan* p, const float* pts1, const float* h4p, const float* U, const float* I2,
+                         const int* idx, const float* M, const float* Minv, float* Hm, float* pred, float* loss,
+                         float* dh4p, unsigned char* ws, hipStream_t s) {
+    const int B = p->B, H = p->H, W = p->W, C = p->C, P = p->P, PP = P * P;
+    const unsigned dflags = p->flags & UH_DLT_SOLVE_F64;
+    float* theta = (float*)(ws + p->off_theta);
+    float* dtheta = (float*)(ws + p->off_dtheta);
+    int e;
+    if ((e = uh_dlt_forward(pts1, h4p, Hm, theta, M, Minv, B, dflags, s))) return e;
+    if (p->flags & UH_TAIL_FUSED_PATCH) {
+        if ((e = uh_warp_patch_l1_fwdbwd(U, theta, I2, idx, pred, loss, dh4p ? dtheta : nullptr, ws + p->off_ws_patch,
+                                         uh_warp_patch_l1_workspace_bytes(B, PP), B, H, W, C, PP, s))) return e;
+    } else {
+        float* warped = (float*)(ws + p->off_warped);
+        float* dwarped = (float*)(ws + p->off_dwarped);
+        float* dpred = (float*)(ws + p->off_dpred);
+        float* one = (float*)(ws + p->off_one);
+        const size_t n = (size_t)B * PP;
+        if ((e = uh_warp_forward(U, theta, warped, nullptr, B, H, W, C, H, W, s))) return e;
+        if ((e = uh_gray_patch_forward(warped, idx, pred, B, H, W, C, PP, s))) return e;
+        if ((e = uh_l1_loss_forward(pred, I2, loss, ws + p->off_ws_l1, uh_l1_loss_workspace_bytes(n), n, s))) return e;
+        if (dh4p) {
+            hipError_t he = hipMemsetD32Async((hipDeviceptr_t)one, 0x3f800000, 1, s);      // dLoss = 1.0f
+            if (he != hipSuccess) return (int)he;
+            if ((e = uh_l1_loss_backward(pred, I2, one, dpred, n, s))) return e;
+            if ((e = uh_gray_patch_backward(dpred, idx, dwarped, B, H, W, C, PP, s))) return e;
+            if ((e = uh_warp_backward(U, theta, dwarped, dtheta, nullptr, ws + p->off_ws_warp,
+                                      uh_warp_backward_workspace_bytes(B, H, W, C, H, W), B, H, W, C, H, W, s))) return e;
+        }
+    }
+    if (dh4p) {
+        if ((e = uh_dlt_backward(pts1, h4p, Hm, nullptr, dtheta, M, Minv, dh4p, B, dflags, s))) return e;
+    }
+    return 0;
+}
+
+extern "C" int uh_tail_run(uh_tail_plan* p, const float* pts1, const float* h4p, const float* U, const float* I2,
+                           const int* patch_idx, const float* M_host, const float* Minv_host, float* H, float* pred,
+                           float* loss, float* dh4p, void* workspace, size_t workspace_bytes, uh_stream_t stream) {
+    if (!p || !pts1 || !h4p || !U || !I2 || !patch_idx || !M_host || !Minv_host || !H || !pred || !loss) return UH_E_NULL;
+    if (!workspace || workspace_bytes < p->total) return UH_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    const bool use_graph = (p->flags & UH_TAIL_GRAPH) && !uh::g_prof_on && s != nullptr;   // capture needs a real stream
+    if (!use_graph) return enqueue_chain(p, pts1, h4p, U, I2, patch_idx, M_host, Minv_host, H, pred, loss, dh4p, ws, s);
+
+    std::lock_guard<std::mutex> lk(p->mu);
+    const void* key[12] = {pts1, h4p, U, I2, patch_idx, H, pred, loss, dh4p, workspace, s, nullptr};
+    float mk[18];
+    std::memcpy(mk, M_host, 9 * sizeof(float)); std::memcpy(mk + 9, Minv_host, 9 * sizeof(float));
+    for (auto& e : p->cache) {
+        if (std::memcmp(e.key, key, sizeof(key)) == 0) {
+            e.stamp = ++p->clock;
+            p->launches++;
+            return (int)hipGraphLaunch(e.exec, s);
+        }
+    }
+    // capture the chain on the caller's stream (thread-local mode: other threads' HIP calls are unaffected)
+    hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (he != hipSuccess) return (int)he;
+    const int ce = enqueue_chain(p, pts1, h4p, U, I2, patch_idx, M_host, Minv_host, H, pred, loss, dh4p, ws, s);
+    hipGraph_t graph = nullptr;
+    he = hipStreamEndCapture(s, &graph);
+    if (ce != 0) { if (graph) (void)hipGraphDestroy(graph); return ce; }
+    if (he != hipSuccess) return (int)he;
+    hipGraphExec_t exec = nullptr;
+    he = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (he != hipSuccess) { (void)hipGraphDestroy(graph); return (int)he; }
+    if (p->cache.size() >= 8) {                      // evict the least recently used instance
+        size_t v = 0;
+        for (size_t i = 1; i < p->cache.size(); ++i) if (p->cache[i].stamp < p->cache[v].stamp) v = i;
+        (void)hipGraphExecDestroy(p->cache[v].exec); (void)hipGraphDestroy(p->cache[v].graph);
+        p->cache.erase(p->cache.begin() + v);
+    }
+    uh_tail_plan::Entry en;
+    std::memcpy(en.key, key, sizeof(key)); en.graph = graph; en.exec = exec; en.stamp = ++p->clock;
+    p->cache.push_back(en);
+    p->captures++; p->launches++;
+    return (int)hipGraphLaunch(exec, s);
+}

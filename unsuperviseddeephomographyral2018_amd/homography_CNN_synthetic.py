@@ -75,6 +75,8 @@ def build_parser():
     p.add_argument('--fused_patch', type=str2bool, default='False',
                    help='l1_loss only: fused patch kernel instead of the full-frame warp')
     p.add_argument('--solve_f64', type=str2bool, default='False', help='carry the 8x8 DLT solve in f64')
+    p.add_argument('--graph_tail', type=str2bool, default='False',
+                   help='l1_loss only: DLT -> warp -> loss and their backward as one library call / one hipGraph launch')
     p.add_argument('--fresh_data_every', type=int, default=1, help='draw a new synthetic batch every N steps')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--log_every', type=int, default=100)
@@ -122,12 +124,25 @@ class TrainStep(object):
 
     def __call__(self, batch):
         """sess.run([apply_grad_opt, ...]) of the hot loop (:333-353): forward, backward, average, Adam."""
+        if getattr(self.args, 'graph_tail', False) and self.device.type == 'cuda':
+            # stream capture needs a real (non-NULL) stream: run the whole step on a private one
+            if not hasattr(self, '_stream'):
+                self._stream = torch.cuda.Stream(device=self.device)
+            self._stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._stream):
+                model = self._step(batch)
+            torch.cuda.current_stream(self.device).wait_stream(self._stream)
+            return model
+        return self._step(batch)
+
+    def _step(self, batch):
         lr = self.learning_rate()
         for g in self.opt.param_groups:
             g['lr'] = lr
         self.averager.reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
-                                net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64)
+                                net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
+                                graph_tail=getattr(self.args, 'graph_tail', False))
         model.loss.backward()
         self.averager.finish()
         self.opt.step()

@@ -103,7 +103,7 @@ def reset_variables():
 
 class HomographyModel(object):
     def __init__(self, args, I1, I2, I1_aug, I2_aug, I_aug, I_prime_aug, h4p, gt, patch_indices,
-                 reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False):
+                 reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False, graph_tail=False):
         self.params = args
         self.mode = args.mode
         self.is_training = True if self.mode == 'train' else False
@@ -123,6 +123,8 @@ class HomographyModel(object):
         # MI355X-side switches (not in the reference): fused patch kernel for the l1 path, f64 DLT solve
         self.fused_patch = fused_patch
         self.solve_f64 = solve_f64
+        # one library call / one hipGraph launch for solve_DLT + transform + l1 loss and their backward (l1_loss only)
+        self.graph_tail = bool(graph_tail) and args.loss_type == 'l1_loss'
         if args.loss_type not in LOSS_TYPES:
             raise ValueError('===> Loss type does not exist! ' + str(args.loss_type))
         # Constants used for the spatial transformer (homography_model.py:63-72): live in ops.m_and_minv
@@ -161,6 +163,14 @@ class HomographyModel(object):
 
     # ---- homography_model.py:169-250 (+ the theta fold of :254) ------------------------------------
     def solve_DLT(self):
+        self._tail = None
+        if self.graph_tail:
+            with torch.set_grad_enabled(self._hot_grad):
+                self._tail = ops.photometric_tail(self.pts_1, self.pred_h4p, self.I, self.I2_aug, self.patch_indices,
+                                                  self.params.patch_size, fused_patch=self.fused_patch, graph=True,
+                                                  solve_f64=self.solve_f64)
+            self.H_mat = self._tail[2]
+            return
         with torch.set_grad_enabled(self._hot_grad):
             self.H_mat, self._theta = ops.solve_dlt(self.pts_1, self.pred_h4p, self.params.img_w,
                                                     self.params.img_h, solve_f64=self.solve_f64)
@@ -172,6 +182,11 @@ class HomographyModel(object):
 
     def _transform(self):
         P = self.params.patch_size
+        if self._tail is not None:              # everything was produced by the tail call in solve_DLT()
+            self._l1_fused, self.pred_I2 = self._tail[0], self._tail[1]
+            if self._tail[3].warped is not None:
+                self.warped_images = self._tail[3].warped
+            return
         out_size = (self.params.img_h, self.params.img_w)
         if self.fused_patch and self.params.loss_type == 'l1_loss':
             # one kernel: sample -> gray -> patch -> |.| -> mean, and d/dtheta; warped frame never exists

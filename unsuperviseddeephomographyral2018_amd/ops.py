@@ -287,3 +287,96 @@ class _WarpPatchL1(torch.autograd.Function):
 def warp_patch_l1(U, theta, I2, patch_indices, patch_size):
     """-> (l1_loss scalar, pred_I2 [B,P,P,1]); pred_I2 carries no gradient on this path."""
     return _WarpPatchL1.apply(U, theta.reshape(-1, 9), I2, patch_indices, patch_size)
+
+
+# ------------------------------------------------------------------------------------------------
+class TailPlan(object):
+    """uh_tail_plan + its persistent workspace for one shape.  Keeping the workspace (and
+    therefore theta / warped / dWarped ...) at fixed addresses is what lets the captured hipGraph be replayed."""
+    _cache = {}
+
+    def __init__(self, B, H, W, Cc, P, device, fused_patch=False, graph=True, solve_f64=False):
+        lib = _lib.load()
+        self.dims = (B, H, W, Cc, P)
+        self.fused = bool(fused_patch)
+        flags = (_lib.UH_TAIL_FUSED_PATCH if fused_patch else 0) | (_lib.UH_TAIL_GRAPH if graph else 0) \
+            | (_lib.UH_DLT_SOLVE_F64 if solve_f64 else 0)
+        h = C.c_void_p()
+        _lib.check(lib.uh_tail_create(C.byref(h), B, H, W, Cc, P, flags), 'uh_tail_create')
+        self.handle = h
+        self.nbytes = lib.uh_tail_workspace_bytes(h)
+        self.ws = torch.empty((self.nbytes,), dtype=torch.uint8, device=device)
+        self.M, self.Minv = m_and_minv(W, H)
+        self._Mh = np.ascontiguousarray(self.M.reshape(9), np.float32)
+        self._Mih = np.ascontiguousarray(self.Minv.reshape(9).astype(np.float32))
+        # plan-owned I/O buffers: fixed addresses = one captured graph serves every step (the results are valid until
+        # the next run of this plan)
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+        self.h4p_in, self.H_out, self.pred_out = f(B, 8), f(B, 3, 3), f(B, P, P, 1)
+        self.loss_out, self.dh4p_out = f(1), f(B, 8)
+        off = lib.uh_tail_warped_offset(h)
+        self.warped = None
+        if not self.fused:
+            n = B * H * W * Cc * 4
+            self.warped = self.ws[off:off + n].view(torch.float32).view(B, H, W, Cc)
+
+    def stats(self):
+        a = C.c_longlong(); b = C.c_longlong()
+        _lib.check(_lib.load().uh_tail_stats(self.handle, C.byref(a), C.byref(b)), 'uh_tail_stats')
+        return {'launches': a.value, 'captures': b.value}
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().uh_tail_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @classmethod
+    def get(cls, B, H, W, Cc, P, device, fused_patch=False, graph=True, solve_f64=False):
+        key = (B, H, W, Cc, P, str(device), bool(fused_patch), bool(graph), bool(solve_f64))
+        if key not in cls._cache:
+            cls._cache[key] = cls(B, H, W, Cc, P, device, fused_patch, graph, solve_f64)
+        return cls._cache[key]
+
+
+class _PhotometricTail(torch.autograd.Function):
+    """(pts1, h4p, U, I2, patch_idx) -> (l1_loss, pred_I2, H) in ONE library call; d loss/d h4p for dLoss = 1 is
+    produced by the same call and scaled in backward."""
+
+    @staticmethod
+    def forward(ctx, pts1, h4p, U, I2, patch_idx, plan):
+        lib = _lib.load()
+        B, H, W, Cc, P = plan.dims
+        pts1 = _f32(pts1, 'pts1').reshape(B, 8); h4p = _f32(h4p, 'h4p').reshape(B, 8)
+        U = _f32(U, 'U'); I2 = _f32(I2, 'I2')
+        if tuple(U.shape) != (B, H, W, Cc) or I2.numel() != B * P * P:
+            raise _lib.UHError('photometric_tail: tensors do not match the plan %s' % (plan.dims,))
+        if patch_idx.dtype != torch.int32 or not patch_idx.is_cuda:
+            raise _lib.UHError('patch_indices must be an int32 tensor on the HIP device')
+        idx = patch_idx.contiguous()
+        plan.h4p_in.copy_(h4p)                   # the regressor's output lands at a fixed address
+        h4p = plan.h4p_in
+        Hm, pred, loss = plan.H_out, plan.pred_out, plan.loss_out
+        need = ctx.needs_input_grad[1]
+        dh4p = plan.dh4p_out if need else None
+        _lib.check(lib.uh_tail_run(plan.handle, _ptr(pts1), _ptr(h4p), _ptr(U), _ptr(I2), _ptr(idx),
+                                   plan._Mh.ctypes.data_as(C.c_void_p), plan._Mih.ctypes.data_as(C.c_void_p), _ptr(Hm),
+                                   _ptr(pred), _ptr(loss), _ptr(dh4p), C.c_void_p(plan.ws.data_ptr()), plan.nbytes,
+                                   _stream()), 'uh_tail_run')
+        ctx.dh4p = dh4p
+        ctx.mark_non_differentiable(pred, Hm)
+        return loss[0], pred, Hm
+
+    @staticmethod
+    def backward(ctx, dLoss, dPred=None, dH=None):
+        return None, (ctx.dh4p * dLoss if ctx.dh4p is not None else None), None, None, None, None
+
+
+def photometric_tail(pts1, h4p, U, I2, patch_indices, patch_size, fused_patch=False, graph=True, solve_f64=False):
+    """-> (l1_loss, pred_I2 [B,P,P,1], H_mat [B,3,3], plan).  plan.warped is the warped frame (full-frame mode)."""
+    B, H, W, Cc = U.shape
+    plan = TailPlan.get(B, H, W, Cc, int(patch_size), U.device, fused_patch, graph, solve_f64)
+    loss, pred, Hm = _PhotometricTail.apply(pts1, h4p, U, I2, patch_indices, plan)
+    return loss, pred, Hm, plan
