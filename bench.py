@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
     ap.add_argument('--graph_tail', type=int, default=0, help='1: DLT->warp->loss and backward as one hipGraph launch')
+    ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object)')
     ap.add_argument('--cpu_baseline', type=int, default=1)
     ap.add_argument('--north_star', type=int, default=1, help='0: skip the extra warp-only measurement at batch 128')
     ap.add_argument('--cpu_sample_pairs', type=int, default=8)
@@ -162,7 +163,7 @@ def main():
     torch.cuda.synchronize(device)
     if world > 1:
         torch.distributed.barrier()
-    _lib.profile_enable(True)
+    _lib.profile_enable(bool(args.profile))
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -196,19 +197,23 @@ def main():
         dom, alg = 'warp_patch_l1_fused', B * args.patch_size ** 2 * (4 * 12 + 12)
     else:
         cands = [k for k in ('warp_forward', 'warp_backward') if k in kern]
-        dom = max(cands, key=lambda k: kern[k]['avg_us'] * kern[k]['launches'])
+        dom = max(cands, key=lambda k: kern[k]['avg_us'] * kern[k]['launches']) if cands else None
         alg = frame_bytes
-    t_dom = kern[dom]['avg_us'] * 1e-6
-    achieved = alg / t_dom
-    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved / 1e9, 1), 'peak': HBM_PEAK / 1e9,
-                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': None,
-                'algorithmic_bytes_per_launch': alg, 'avg_launch_us': kern[dom]['avg_us'],
-                'timing': 'hipEvent pairs on the launch stream inside the timed region (uh_profile_*)',
-                'kernels': kern}
+    if dom is None:                                        # --profile 0: no per-kernel events were taken
+        roofline = {'bound': 'hbm', 'kernel': None, 'achieved': None, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                    'frac': None, 'traffic': None, 'note': 'per-kernel timing disabled (--profile 0)'}
+    else:
+        t_dom = kern[dom]['avg_us'] * 1e-6
+        achieved = alg / t_dom
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved / 1e9, 1), 'peak': HBM_PEAK / 1e9,
+                    'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK, 4), 'traffic': None,
+                    'algorithmic_bytes_per_launch': alg, 'avg_launch_us': kern[dom]['avg_us'],
+                    'timing': 'HIP start/stop events of each dispatch on its launch stream (hipExtLaunchKernelGGL via '
+                              'uh_profile_*), inside the timed region', 'kernels': kern}
     # HBM bytes per launch of the dominant kernel from the PMC passes over THIS command (tools/gpu_traffic.sh ->
     # profiles/traffic_r01.json; FETCH_SIZE x2 KiB + WRITE_SIZE KiB, the gfx950 correction calibrated on a device copy)
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
-    if os.path.exists(traffic_file):
+    if dom is not None and os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             key = '%s_B%d_%dx%d' % (dom, B, args.img_h, args.img_w)

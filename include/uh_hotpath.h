@@ -175,6 +175,15 @@ UH_API int    uh_tail_run(uh_tail_plan* plan, const float* pts1, const float* h4
 UH_API int    uh_tail_stats(const uh_tail_plan* plan, long long* launches, long long* captures);
 UH_API void   uh_tail_destroy(uh_tail_plan* plan);
 
+/* ---- bias + ReLU epilogue of the regressor's conv layers (outside the reference's hot path; conv GEMMs stay MIOpen) --
+ * y [npix, C] NHWC activation (npix = N*H*W), C % 4 == 0 and 1024 % C == 0.   homography_model.py:88-95 (_conv2d)
+ *   forward : y <- max(y + bias[c], 0) in place
+ *   backward: g = (y > 0) ? gy : 0 ; dbias[c] = sum g     (deterministic two-stage reduction through `workspace`)      */
+UH_API int    uh_bias_relu_forward(float* y, const float* bias, size_t npix, int C, uh_stream_t stream);
+UH_API size_t uh_bias_relu_backward_workspace_bytes(size_t npix, int C);
+UH_API int    uh_bias_relu_backward(const float* y, const float* gy, float* g, float* dbias, void* workspace,
+                             size_t workspace_bytes, size_t npix, int C, uh_stream_t stream);
+
 /* ---- in-library kernel timing (used by bench.py for the roofline figure) -----------------------------
  * When enabled, every launch above is bracketed by hipEventRecord on ITS stream; uh_profile_read()
  * synchronises those events and accumulates per-kernel totals.  Not thread-safe while enabled.      */
@@ -192,7 +201,9 @@ UH_API void   uh_tail_destroy(uh_tail_plan* plan);
 #define UH_K_LOSSES        11
 #define UH_K_LOSSES_FIN    12
 #define UH_K_PREPARE       13
-#define UH_K_COUNT         14
+#define UH_K_EPI_FWD       14
+#define UH_K_EPI_BWD       15
+#define UH_K_COUNT         16
 UH_API int uh_profile_enable(int on);                        /* returns previous state; resets counters  */
 UH_API int uh_profile_read(double* total_ms /*[UH_K_COUNT]*/, long long* launches /*[UH_K_COUNT]*/);
 UH_API const char* uh_kernel_name(int k);

@@ -196,3 +196,34 @@ def test_graph_tail_equals_unfused_chain(pkg, dev, fused):
         assert torch.equal(plan.warped, wa)
     st = plan.stats()
     assert st['captures'] >= 1 and st['launches'] >= 3 and st['captures'] <= st['launches'] - 2, st
+
+
+def test_conv_bias_relu_epilogue_equals_torch(pkg, dev):
+    """ops.conv_bias_relu (MIOpen conv + HIP bias/ReLU epilogue) vs F.relu(F.conv2d(x, w, b)): same forward bits,
+    gradients within f32 reduction-order noise; and the whole regressor with / without the fused epilogue."""
+    hm, synthetic, _ = pkg
+    from unsuperviseddeephomographyral2018_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device=dev).manual_seed(0)
+    for (N, Ci, Co, S) in ((3, 2, 64, 32), (2, 64, 128, 16)):
+        x = torch.randn(N, Ci, S, S, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(Co, Ci, 3, 3, generator=g, device=dev) * 0.1).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(Co, generator=g, device=dev)
+        gy = torch.randn(N, Co, S, S, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+        outs = []
+        for fused in (False, True):
+            xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, b))
+            y = ops.conv_bias_relu(xi, wi, bi, 1) if fused else F.relu(F.conv2d(xi, wi, bi, 1, 1))
+            y.backward(gy)
+            outs.append((y.detach(), xi.grad, wi.grad, bi.grad))
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-5)
+        for k in (1, 2, 3):
+            ref = outs[0][k]; got = outs[1][k]
+            assert (got - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max())), k
+    batch = synthetic.make_batch(B, H, W, P, RHO, seed=5, device=dev)
+    torch.manual_seed(1)
+    net = hm.VGGRegressor(P).to(dev).to(memory_format=torch.channels_last).eval()
+    xin = torch.cat([batch['I1_aug'], batch['I2_aug']], 3)
+    net.fused_epilogue = True; a = net(xin)
+    net.fused_epilogue = False; b2 = net(xin)
+    assert torch.allclose(a, b2, rtol=1e-4, atol=1e-4)

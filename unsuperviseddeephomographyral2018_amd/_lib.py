@@ -12,7 +12,7 @@ UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
 UH_TAIL_FUSED_PATCH = 2
 UH_TAIL_GRAPH = 4
-KERNEL_COUNT = 14
+KERNEL_COUNT = 16
 
 _p = C.c_void_p
 _i = C.c_int
@@ -44,6 +44,9 @@ SIGNATURES = {
     'uh_tail_run': (_i, [_p] * 12 + [_p, _z, _p]),
     'uh_tail_stats': (_i, [_p, _p, _p]),
     'uh_tail_destroy': (None, [_p]),
+    'uh_bias_relu_forward': (_i, [_p, _p, _z, _i, _p]),
+    'uh_bias_relu_backward_workspace_bytes': (_z, [_z, _i]),
+    'uh_bias_relu_backward': (_i, [_p, _p, _p, _p, _p, _z, _z, _i, _p]),
     'uh_profile_enable': (_i, [_i]),
     'uh_profile_read': (_i, [_p, _p]),
     'uh_kernel_name': (C.c_char_p, [_i]),

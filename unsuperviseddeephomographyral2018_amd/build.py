@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libuh_hotpath.so')
-SOURCES = ['uh_dlt.hip', 'uh_warp.hip', 'uh_misc.hip', 'uh_patch.hip', 'uh_losses.hip', 'uh_inputs.hip', 'uh_tail.hip']
+SOURCES = ['uh_dlt.hip', 'uh_warp.hip', 'uh_misc.hip', 'uh_patch.hip', 'uh_losses.hip', 'uh_inputs.hip', 'uh_tail.hip', 'uh_epilogue.hip']
 HEADERS = ['uh_device.h', 'uh_host.h', os.path.join('..', '..', 'include', 'uh_hotpath.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared',
          '-fvisibility=hidden', '-Wall', '-Wno-unused-function']

@@ -138,7 +138,8 @@ extern "C" const char* uh_kernel_name(int k) {
     static const char* names[UH_K_COUNT] = {"dlt_forward", "dlt_backward", "warp_forward", "warp_backward",
                                             "warp_backward_finish", "gray_patch_forward", "gray_patch_backward",
                                             "l1_forward", "l1_backward", "warp_patch_l1_fused", "warp_patch_l1_finish",
-                                            "patch_losses", "patch_losses_finish", "prepare_inputs"};
+                                            "patch_losses", "patch_losses_finish", "prepare_inputs",
+                                            "bias_relu_forward", "bias_relu_backward"};
     return (k >= 0 && k < UH_K_COUNT) ? names[k] : "?";
 }
 

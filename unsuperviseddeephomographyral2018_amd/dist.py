@@ -29,12 +29,16 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        # one process per GPU; UH_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the N > 1
+        # code path on a 1-GPU box) -- RCCL itself needs one device per rank
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'     # "nccl" IS RCCL on ROCm
-        if backend == 'nccl':
+            backend = os.environ.get('UH_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():                                      # "nccl" IS RCCL on ROCm
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

@@ -49,8 +49,10 @@ class VGGRegressor(nn.Module):
     weights, zero biases.  Optional BN keeps the reference's quirk: is_training is passed as the
     *decay* (:93), i.e. decay=1 -> moving statistics never move (momentum 0 here)."""
 
-    def __init__(self, patch_size=128, use_batch_norm=False):
+    def __init__(self, patch_size=128, use_batch_norm=False, fused_epilogue=True):
         super().__init__()
+        # conv GEMMs on stock MIOpen; bias + ReLU (+ their backward and the bias gradient) as one HIP pass each
+        self.fused_epilogue = fused_epilogue
         chans = [(2, 64), (64, 64), (64, 64), (64, 64), (64, 128), (128, 128), (128, 128), (128, 128)]
         self.convs = nn.ModuleList([nn.Conv2d(i, o, 3, stride=1, padding=1) for i, o in chans])
         self.use_batch_norm = use_batch_norm
@@ -66,6 +68,8 @@ class VGGRegressor(nn.Module):
             nn.init.zeros_(m.bias)
 
     def _conv(self, x, i):
+        if self.fused_epilogue and not self.use_batch_norm and x.is_cuda and x.dtype == torch.float32:
+            return ops.conv_bias_relu(x, self.convs[i].weight, self.convs[i].bias, 1)
         x = F.relu(self.convs[i](x))
         if self.use_batch_norm:
             x = self.bns[i](x)

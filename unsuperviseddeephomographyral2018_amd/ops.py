@@ -380,3 +380,46 @@ def photometric_tail(pts1, h4p, U, I2, patch_indices, patch_size, fused_patch=Fa
     plan = TailPlan.get(B, H, W, Cc, int(patch_size), U.device, fused_patch, graph, solve_f64)
     loss, pred, Hm = _PhotometricTail.apply(pts1, h4p, U, I2, patch_indices, plan)
     return loss, pred, Hm, plan
+
+
+# ------------------------------------------------------------------------------------------------
+class _ConvBiasReLU(torch.autograd.Function):
+    """relu(conv2d(x, w) + b) with the conv on stock MIOpen and the bias+ReLU epilogue (and its backward, including
+    the bias gradient) as one HIP pass each (csrc/uh_epilogue.hip).  Activations are channels_last (NHWC storage)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding):
+        lib = _lib.load()
+        y = torch.nn.functional.conv2d(x, weight, None, 1, padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        N, Cc, Hh, Ww = y.shape
+        _lib.check(lib.uh_bias_relu_forward(_ptr(y), _ptr(_f32(bias, 'bias')), N * Hh * Ww, Cc, _stream()),
+                   'uh_bias_relu_forward')
+        ctx.save_for_backward(x, weight, y)
+        ctx.padding = padding
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, weight, y = ctx.saved_tensors
+        N, Cc, Hh, Ww = y.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        g = torch.empty_like(y, memory_format=torch.channels_last)
+        db = torch.empty((Cc,), dtype=torch.float32, device=y.device)
+        npix = N * Hh * Ww
+        nbytes = lib.uh_bias_relu_backward_workspace_bytes(npix, Cc)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=y.device)
+        _lib.check(lib.uh_bias_relu_backward(_ptr(y), _ptr(gy), _ptr(g), _ptr(db), _ptr(ws), nbytes, npix, Cc, _stream()),
+                   'uh_bias_relu_backward')
+        p = ctx.padding
+        dx, dw, _ = torch.ops.aten.convolution_backward(
+            g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
+
+
+def conv_bias_relu(x, weight, bias, padding=1):
+    """relu(conv2d(x, weight, bias, stride 1, padding)) -- homography_model.py:88-95 (_conv2d without batch norm)."""
+    return _ConvBiasReLU.apply(x, weight, bias, padding)
