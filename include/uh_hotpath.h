@@ -184,6 +184,14 @@ UH_API size_t uh_bias_relu_backward_workspace_bytes(size_t npix, int C);
 UH_API int    uh_bias_relu_backward(const float* y, const float* gy, float* g, float* dbias, void* workspace,
                              size_t workspace_bytes, size_t npix, int C, uh_stream_t stream);
 
+/* the same fused with the 2x2/2 max-pool that follows (homography_model.py:102-105): y [N,H,W,C] (H, W even) is
+ * rewritten in place with relu(y + b) and kept for the backward; pooled / gpooled [N,H/2,W/2,C].                      */
+UH_API int    uh_bias_relu_pool_forward(float* y, const float* bias, float* pooled, int N, int H, int W, int C,
+                                 uh_stream_t stream);
+UH_API size_t uh_bias_relu_pool_backward_workspace_bytes(int N, int H, int W, int C);
+UH_API int    uh_bias_relu_pool_backward(const float* y, const float* gpooled, float* g, float* dbias, void* workspace,
+                                  size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream);
+
 /* ---- in-library kernel timing (used by bench.py for the roofline figure) -----------------------------
  * When enabled, every launch above is bracketed by hipEventRecord on ITS stream; uh_profile_read()
  * synchronises those events and accumulates per-kernel totals.  Not thread-safe while enabled.      */

@@ -220,10 +220,33 @@ def test_conv_bias_relu_epilogue_equals_torch(pkg, dev):
         for k in (1, 2, 3):
             ref = outs[0][k]; got = outs[1][k]
             assert (got - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max())), k
+    # + the 2x2/2 max-pool fused into the epilogue
+    for (N, Ci, Co, S) in ((2, 64, 64, 32), (3, 64, 128, 8)):
+        x = torch.randn(N, Ci, S, S, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(Co, Ci, 3, 3, generator=g, device=dev) * 0.1).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(Co, generator=g, device=dev)
+        gp = torch.randn(N, Co, S // 2, S // 2, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
+        outs = []
+        for fused in (False, True):
+            xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, b))
+            y = ops.conv_bias_relu_pool(xi, wi, bi, 1) if fused else F.max_pool2d(F.relu(F.conv2d(xi, wi, bi, 1, 1)), 2, 2)
+            y.backward(gp)
+            outs.append((y.detach(), xi.grad, wi.grad, bi.grad))
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-5)
+        for k in (1, 2, 3):
+            ref = outs[0][k]; got = outs[1][k]
+            assert (got - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max())), ('pool', k)
     batch = synthetic.make_batch(B, H, W, P, RHO, seed=5, device=dev)
     torch.manual_seed(1)
     net = hm.VGGRegressor(P).to(dev).to(memory_format=torch.channels_last).eval()
     xin = torch.cat([batch['I1_aug'], batch['I2_aug']], 3)
-    net.fused_epilogue = True; a = net(xin)
-    net.fused_epilogue = False; b2 = net(xin)
-    assert torch.allclose(a, b2, rtol=1e-4, atol=1e-4)
+    res = []
+    for fused in (True, False):
+        net.fused_epilogue = fused
+        net.zero_grad(set_to_none=True)
+        o = net(xin)
+        o.square().mean().backward()
+        res.append((o.detach(), [p.grad.clone() for p in net.parameters()]))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-4, atol=1e-4)
+    for ga, gb in zip(res[0][1], res[1][1]):
+        assert (ga - gb).abs().max() <= 1e-3 * max(1e-6, float(gb.abs().max()))

@@ -47,6 +47,9 @@ SIGNATURES = {
     'uh_bias_relu_forward': (_i, [_p, _p, _z, _i, _p]),
     'uh_bias_relu_backward_workspace_bytes': (_z, [_z, _i]),
     'uh_bias_relu_backward': (_i, [_p, _p, _p, _p, _p, _z, _z, _i, _p]),
+    'uh_bias_relu_pool_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    'uh_bias_relu_pool_backward_workspace_bytes': (_z, [_i, _i, _i, _i]),
+    'uh_bias_relu_pool_backward': (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     'uh_profile_enable': (_i, [_i]),
     'uh_profile_read': (_i, [_p, _p]),
     'uh_kernel_name': (C.c_char_p, [_i]),

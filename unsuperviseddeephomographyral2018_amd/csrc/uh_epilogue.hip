@@ -76,6 +76,75 @@ __global__ __launch_bounds__(1024) void bias_grad_finish_kernel(const float* __r
     }
 }
 
+// ---- the same epilogue fused with the 2x2/2 max-pool that follows the second conv of a block (_maxpool2d, :102-105) ----
+// forward : y <- max(y + b, 0) in place (kept for the backward), p[n, i, j, c] = max of the 2x2 window of y
+// backward: g = gp[n, i/2, j/2, c] where y is the (first) maximum of its window and y > 0, else 0; db[c] = sum g.
+// A window whose four values tie (typically all 0 after the ReLU) routes the gradient to its first element, as
+// max_pool2d does -- where the ReLU mask then zeroes it anyway.  One thread = one pooled pixel x one channel quad.
+__device__ __forceinline__ float4 relu_bias4(float4 v, float4 b) {
+    return make_float4(fmaxf(v.x + b.x, 0.f), fmaxf(v.y + b.y, 0.f), fmaxf(v.z + b.z, 0.f), fmaxf(v.w + b.w, 0.f));
+}
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+__global__ __launch_bounds__(256) void bias_relu_pool_forward_kernel(float4* __restrict__ y, const float* __restrict__ bias,
+                                                                     float4* __restrict__ p, size_t nq, int Hp, int Wp,
+                                                                     int q /* = C/4 */) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float4 b = *reinterpret_cast<const float4*>(bias + (int)(t % (size_t)q) * 4);
+    const size_t stride = (size_t)gridDim.x * 256;          // multiple of q: the channel quad never changes
+    const size_t rowq = (size_t)2 * Wp * q;                  // float4s per input row
+    for (size_t i = t; i < nq; i += stride) {
+        const size_t pix = i / q; const int cq = (int)(i - pix * q);
+        const size_t n_i = pix / Wp; const int j = (int)(pix - n_i * Wp);      // n_i = n*Hp + i
+        const size_t base = (n_i * 2) * rowq + (size_t)(2 * j) * q + cq;       // (n, 2i, 2j, cq)
+        const float4 a0 = relu_bias4(y[base], b), a1 = relu_bias4(y[base + q], b);
+        const float4 a2 = relu_bias4(y[base + rowq], b), a3 = relu_bias4(y[base + rowq + q], b);
+        y[base] = a0; y[base + q] = a1; y[base + rowq] = a2; y[base + rowq + q] = a3;
+        p[i] = max4(max4(a0, a1), max4(a2, a3));
+    }
+}
+
+__device__ __forceinline__ void route(float y0, float y1, float y2, float y3, float gp, float& g0, float& g1, float& g2, float& g3) {
+    const float m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+    const float live = m > 0.f ? gp : 0.f;                   // ReLU mask of the selected element
+    const bool s0 = y0 == m, s1 = !s0 && y1 == m, s2 = !s0 && !s1 && y2 == m, s3 = !s0 && !s1 && !s2;
+    g0 = s0 ? live : 0.f; g1 = s1 ? live : 0.f; g2 = s2 ? live : 0.f; g3 = s3 ? live : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bias_relu_pool_backward_kernel(const float4* __restrict__ y, const float4* __restrict__ gp,
+                                                                      float4* __restrict__ g, float* __restrict__ partial,
+                                                                      size_t nq, int Hp, int Wp, int q) {
+    __shared__ float4 sm[256];
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t rowq = (size_t)2 * Wp * q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = t; i < nq; i += stride) {
+        const size_t pix = i / q; const int cq = (int)(i - pix * q);
+        const size_t n_i = pix / Wp; const int j = (int)(pix - n_i * Wp);
+        const size_t base = (n_i * 2) * rowq + (size_t)(2 * j) * q + cq;
+        const float4 a0 = y[base], a1 = y[base + q], a2 = y[base + rowq], a3 = y[base + rowq + q];
+        const float4 d = gp[i];
+        float4 g0, g1, g2, g3;
+        route(a0.x, a1.x, a2.x, a3.x, d.x, g0.x, g1.x, g2.x, g3.x);
+        route(a0.y, a1.y, a2.y, a3.y, d.y, g0.y, g1.y, g2.y, g3.y);
+        route(a0.z, a1.z, a2.z, a3.z, d.z, g0.z, g1.z, g2.z, g3.z);
+        route(a0.w, a1.w, a2.w, a3.w, d.w, g0.w, g1.w, g2.w, g3.w);
+        g[base] = g0; g[base + q] = g1; g[base + rowq] = g2; g[base + rowq + q] = g3;
+        acc.x += (g0.x + g1.x) + (g2.x + g3.x); acc.y += (g0.y + g1.y) + (g2.y + g3.y);
+        acc.z += (g0.z + g1.z) + (g2.z + g3.z); acc.w += (g0.w + g1.w) + (g2.w + g3.w);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < q) {
+        float4 s = sm[threadIdx.x];
+        for (int k = threadIdx.x + q; k < 256; k += q) { const float4 v = sm[k]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * q * 4 + threadIdx.x * 4) = s;
+    }
+}
+
 static unsigned epi_grid(size_t n4) {
     const size_t g = (n4 + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > (size_t)EPI_BLOCKS ? (size_t)EPI_BLOCKS : g));
@@ -115,6 +184,46 @@ extern "C" int uh_bias_relu_backward(const float* y, const float* gy, float* g, 
     hipStream_t s = (hipStream_t)stream;
     launch_timed(UH_K_EPI_BWD, bias_relu_backward_kernel, dim3(grid), dim3(256), s, reinterpret_cast<const float4*>(y),
                  reinterpret_cast<const float4*>(gy), reinterpret_cast<float4*>(g), (float*)workspace, n4, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
+    return (int)hipGetLastError();
+}
+
+// ---- with the 2x2/2 max-pool ---------------------------------------------------------------------------
+// y [N,H,W,C] (H, W even), p / gp [N,H/2,W/2,C].  npool = N * (H/2) * (W/2).
+static int check_pool(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return UH_E_SHAPE;
+    return check_epi((size_t)N * H * W, C);
+}
+
+extern "C" int uh_bias_relu_pool_forward(float* y, const float* bias, float* pooled, int N, int H, int W, int C,
+                                         uh_stream_t stream) {
+    if (!y || !bias || !pooled) return UH_E_NULL;
+    if (int e = check_pool(N, H, W, C)) return e;
+    const int q = C / 4;
+    const size_t nq = (size_t)N * (H / 2) * (W / 2) * q;
+    launch_timed(UH_K_EPI_FWD, bias_relu_pool_forward_kernel, dim3(epi_grid(nq)), dim3(256), (hipStream_t)stream,
+                 reinterpret_cast<float4*>(y), bias, reinterpret_cast<float4*>(pooled), nq, H / 2, W / 2, q);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t uh_bias_relu_pool_backward_workspace_bytes(int N, int H, int W, int C) {
+    if (check_pool(N, H, W, C)) return 0;
+    return (size_t)epi_grid((size_t)N * (H / 2) * (W / 2) * (C / 4)) * C * sizeof(float);
+}
+
+extern "C" int uh_bias_relu_pool_backward(const float* y, const float* gpooled, float* g, float* dbias, void* workspace,
+                                          size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream) {
+    if (!y || !gpooled || !g || !dbias) return UH_E_NULL;
+    if (int e = check_pool(N, H, W, C)) return e;
+    if (!workspace || workspace_bytes < uh_bias_relu_pool_backward_workspace_bytes(N, H, W, C)) return UH_E_WORKSPACE;
+    const int q = C / 4;
+    const size_t nq = (size_t)N * (H / 2) * (W / 2) * q;
+    const unsigned grid = epi_grid(nq);
+    hipStream_t s = (hipStream_t)stream;
+    launch_timed(UH_K_EPI_BWD, bias_relu_pool_backward_kernel, dim3(grid), dim3(256), s, reinterpret_cast<const float4*>(y),
+                 reinterpret_cast<const float4*>(gpooled), reinterpret_cast<float4*>(g), (float*)workspace, nq, H / 2, W / 2, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);

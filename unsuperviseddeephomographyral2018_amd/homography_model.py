@@ -67,8 +67,17 @@ class VGGRegressor(nn.Module):
             nn.init.xavier_uniform_(m.weight)
             nn.init.zeros_(m.bias)
 
+    def _fusable(self, x):
+        return self.fused_epilogue and not self.use_batch_norm and x.is_cuda and x.dtype == torch.float32
+
+    def _conv_pool(self, x, i):
+        """second conv of a block followed by the 2x2/2 max-pool (homography_model.py:109-117)"""
+        if self._fusable(x) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            return ops.conv_bias_relu_pool(x, self.convs[i].weight, self.convs[i].bias, 1)
+        return F.max_pool2d(self._conv(x, i), 2, 2)
+
     def _conv(self, x, i):
-        if self.fused_epilogue and not self.use_batch_norm and x.is_cuda and x.dtype == torch.float32:
+        if self._fusable(x):
             return ops.conv_bias_relu(x, self.convs[i].weight, self.convs[i].bias, 1)
         x = F.relu(self.convs[i](x))
         if self.use_batch_norm:
@@ -78,12 +87,9 @@ class VGGRegressor(nn.Module):
     def forward(self, model_input_nhwc):
         # [B,P,P,2] NHWC -> NCHW-logical view with channels_last strides (no copy)
         x = model_input_nhwc.permute(0, 3, 1, 2)
-        x = self._conv(self._conv(x, 0), 1)
-        x = F.max_pool2d(x, 2, 2)
-        x = self._conv(self._conv(x, 2), 3)
-        x = F.max_pool2d(x, 2, 2)
-        x = self._conv(self._conv(x, 4), 5)
-        x = F.max_pool2d(x, 2, 2)
+        x = self._conv_pool(self._conv(x, 0), 1)
+        x = self._conv_pool(self._conv(x, 2), 3)
+        x = self._conv_pool(self._conv(x, 4), 5)
         x = self._conv(self._conv(x, 6), 7)
         x = F.dropout(x, 0.5, self.training)
         x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)          # slim.flatten of NHWC

@@ -423,3 +423,46 @@ class _ConvBiasReLU(torch.autograd.Function):
 def conv_bias_relu(x, weight, bias, padding=1):
     """relu(conv2d(x, weight, bias, stride 1, padding)) -- homography_model.py:88-95 (_conv2d without batch norm)."""
     return _ConvBiasReLU.apply(x, weight, bias, padding)
+
+
+class _ConvBiasReLUPool(torch.autograd.Function):
+    """max_pool2d(relu(conv2d(x, w) + b), 2, 2): the epilogue also produces the pooled map, and its backward routes the
+    pooled gradient straight to the conv output (no full-resolution gradient of the pool in between)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding):
+        lib = _lib.load()
+        y = torch.nn.functional.conv2d(x, weight, None, 1, padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        N, Cc, Hh, Ww = y.shape
+        pooled = torch.empty((N, Cc, Hh // 2, Ww // 2), dtype=torch.float32, device=y.device,
+                             memory_format=torch.channels_last)
+        _lib.check(lib.uh_bias_relu_pool_forward(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(pooled), N, Hh, Ww, Cc, _stream()),
+                   'uh_bias_relu_pool_forward')
+        ctx.save_for_backward(x, weight, y)
+        ctx.padding = padding
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gp):
+        lib = _lib.load()
+        x, weight, y = ctx.saved_tensors
+        N, Cc, Hh, Ww = y.shape
+        gp = gp.contiguous(memory_format=torch.channels_last)
+        g = torch.empty_like(y, memory_format=torch.channels_last)
+        db = torch.empty((Cc,), dtype=torch.float32, device=y.device)
+        nbytes = lib.uh_bias_relu_pool_backward_workspace_bytes(N, Hh, Ww, Cc)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=y.device)
+        _lib.check(lib.uh_bias_relu_pool_backward(_ptr(y), _ptr(gp), _ptr(g), _ptr(db), _ptr(ws), nbytes, N, Hh, Ww, Cc,
+                                                  _stream()), 'uh_bias_relu_pool_backward')
+        p = ctx.padding
+        dx, dw, _ = torch.ops.aten.convolution_backward(
+            g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
+
+
+def conv_bias_relu_pool(x, weight, bias, padding=1):
+    """max_pool2d(relu(conv2d(x, weight, bias)), 2, 2) -- _conv2d + _maxpool2d (homography_model.py:88-105); H, W even."""
+    return _ConvBiasReLUPool.apply(x, weight, bias, padding)
