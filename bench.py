@@ -46,7 +46,8 @@ def parse():
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
     ap.add_argument('--graph_tail', type=int, default=0, help='1: DLT->warp->loss and backward as one hipGraph launch')
-    ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object)')
+    ap.add_argument('--step_graph', type=int, default=0, help='1: whole training step as one hipGraph replay (implies --profile 0)')
+    ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object); 1: time the warp kernels; 2: time every library kernel')
     ap.add_argument('--cpu_baseline', type=int, default=1)
     ap.add_argument('--north_star', type=int, default=1, help='0: skip the extra warp-only measurement at batch 128')
     ap.add_argument('--cpu_sample_pairs', type=int, default=8)
@@ -150,7 +151,9 @@ def main():
         '--mode', 'train', '--loss_type', args.loss_type, '--batch_size', str(B * world),
         '--img_h', str(args.img_h), '--img_w', str(args.img_w), '--patch_size', str(args.patch_size),
         '--rho', str(args.rho), '--fused_patch', 'True' if args.fused_patch else 'False',
-        '--graph_tail', 'True' if args.graph_tail else 'False'])
+        '--graph_tail', 'True' if args.graph_tail else 'False', '--step_graph', 'True' if args.step_graph else 'False'])
+    if args.step_graph:
+        args.profile = 0                                    # per-kernel events cannot be inserted into a replayed graph
     step_fn = TrainStep(targs, device, world)
     # synthetic pairs, generated once, resident in HBM before the timed region; each rank its own shard
     batch = synthetic.make_batch(B, args.img_h, args.img_w, args.patch_size, args.rho, seed=100 + rank,
@@ -163,7 +166,10 @@ def main():
     torch.cuda.synchronize(device)
     if world > 1:
         torch.distributed.barrier()
-    _lib.profile_enable(bool(args.profile))
+    # profile 1 (default): time only the kernels the roofline object reports -- every timed dispatch costs a small
+    # pipeline bubble, and with ~25 library launches per step timing all of them would cost ~10 % of the step
+    hot = ('warp_forward', 'warp_backward', 'warp_backward_finish', 'warp_patch_l1_fused', 'warp_patch_l1_finish')
+    _lib.profile_enable(bool(args.profile), only=None if args.profile == 2 else hot)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -212,7 +212,10 @@ UH_API int    uh_bias_relu_pool_backward(const float* y, const float* gpooled, f
 #define UH_K_EPI_FWD       14
 #define UH_K_EPI_BWD       15
 #define UH_K_COUNT         16
-UH_API int uh_profile_enable(int on);                        /* returns previous state; resets counters  */
+/* on = 0: off; 1: time every kernel; otherwise a mask: bit (k + 1) set = time kernel UH_K_k only (timing a dispatch
+ * costs a few us of pipeline bubble, so a throughput run times just the kernels it reports).  Returns the previous
+ * on/off state; resets the counters.                                                                              */
+UH_API int uh_profile_enable(int on);
 UH_API int uh_profile_read(double* total_ms /*[UH_K_COUNT]*/, long long* launches /*[UH_K_COUNT]*/);
 UH_API const char* uh_kernel_name(int k);
 

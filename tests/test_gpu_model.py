@@ -101,6 +101,12 @@ def test_end_to_end_gradient_vs_cpu_op_graph(pkg, dev):
     torch.manual_seed(1)
     net = hm.VGGRegressor(P).eval()
     net_gpu = copy.deepcopy(net).to(dev).to(memory_format=torch.channels_last).eval()
+    # This test pins the HOT PATH's gradient chain, so the regressor runs on the stock torch conv+bias+ReLU+pool ops
+    # (bitwise reproducible forward).  With the fused epilogue MIOpen is called without a bias and may pick a split-K
+    # (atomic) forward solver: activations then vary by ~1e-7 from run to run, which on these smooth inputs flips a few
+    # near-tied max-pool winners and moves the early layers' gradients by ~1e-3 -- legitimate f32 behaviour, but not what
+    # a 2e-3 comparison against a CPU graph can pin.  The epilogue has its own tests (op level and whole regressor).
+    net_gpu.fused_epilogue = False
     m = hm.HomographyModel(params(hm, 'test', B, P, W, H, 'l1_loss'), *synthetic.model_args(batch), net=net_gpu)
     m.l1_loss.backward()
     cb = {k: v.cpu() for k, v in batch.items()}

@@ -86,8 +86,22 @@ def check(code, what):
         raise UHError('%s failed: %s (code %d)' % (what, load().uh_error_string(code).decode(), code))
 
 
-def profile_enable(on):
-    return load().uh_profile_enable(1 if on else 0)
+KERNEL_IDS = {'dlt_forward': 0, 'dlt_backward': 1, 'warp_forward': 2, 'warp_backward': 3, 'warp_backward_finish': 4,
+              'gray_patch_forward': 5, 'gray_patch_backward': 6, 'l1_forward': 7, 'l1_backward': 8,
+              'warp_patch_l1_fused': 9, 'warp_patch_l1_finish': 10, 'patch_losses': 11, 'patch_losses_finish': 12,
+              'prepare_inputs': 13, 'bias_relu_forward': 14, 'bias_relu_backward': 15}
+
+
+def profile_enable(on, only=None):
+    """on: bool.  only: iterable of kernel names (KERNEL_IDS) to time; None = every kernel."""
+    if not on:
+        return load().uh_profile_enable(0)
+    if only is None:
+        return load().uh_profile_enable(1)
+    mask = 0
+    for name in only:
+        mask |= 1 << (KERNEL_IDS[name] + 1)
+    return load().uh_profile_enable(mask)
 
 
 def profile_read():

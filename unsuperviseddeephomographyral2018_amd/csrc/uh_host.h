@@ -10,6 +10,7 @@ namespace uh {
 // launch they bracket, so the figure is the kernel's device-side duration plus the event overhead,
 // not host wall time.  Disabled -> zero cost beyond one branch.
 extern bool g_prof_on;
+extern unsigned g_prof_mask;      // bit k set = kernel k is timed
 void prof_begin(int kernel, hipStream_t s);
 void prof_end(int kernel, hipStream_t s);
 
@@ -21,7 +22,7 @@ void prof_pair(int kernel, hipEvent_t* a, hipEvent_t* b);
 // launch `kernel`; when the profiler is on, time exactly this dispatch
 template <typename K, typename... Args>
 inline void launch_timed(int kid, K kernel, dim3 grid, dim3 block, hipStream_t s, Args... args) {
-    if (g_prof_on) {
+    if (g_prof_on && ((g_prof_mask >> kid) & 1u)) {
         hipEvent_t a, b;
         prof_pair(kid, &a, &b);
         hipExtLaunchKernelGGL(kernel, grid, block, 0, s, a, b, 0, args...);
@@ -32,7 +33,7 @@ inline void launch_timed(int kid, K kernel, dim3 grid, dim3 block, hipStream_t s
 
 struct ProfScope {
     int k; hipStream_t s; bool on;
-    ProfScope(int kernel, hipStream_t stream) : k(kernel), s(stream), on(g_prof_on) { if (on) prof_begin(k, s); }
+    ProfScope(int kernel, hipStream_t stream) : k(kernel), s(stream), on(g_prof_on && ((g_prof_mask >> kernel) & 1u)) { if (on) prof_begin(k, s); }
     ~ProfScope() { if (on) prof_end(k, s); }
 };
 

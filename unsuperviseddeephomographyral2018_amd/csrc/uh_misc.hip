@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void l1_backward_kernel(const float* __restric
 
 // ---- launch profiler -----------------------------------------------------------------------------
 bool g_prof_on = false;
+unsigned g_prof_mask = 0xffffffffu;
 namespace {
 struct Rec { int k; hipEvent_t a, b; };
 std::mutex g_mu;
@@ -151,6 +152,8 @@ extern "C" int uh_profile_enable(int on) {
     g_done.clear(); g_open.clear();
     for (int i = 0; i < UH_K_COUNT; ++i) { g_ms[i] = 0; g_n[i] = 0; }
     g_prof_on = on != 0;
+    // on == 1: every kernel; otherwise bit (k + 1) of `on` selects kernel k (UH_K_*), e.g. (1 << (UH_K_WARP_FWD + 1))
+    g_prof_mask = (on == 1 || on == 0) ? 0xffffffffu : ((unsigned)on >> 1);
     return prev;
 }
 

@@ -75,6 +75,8 @@ def build_parser():
     p.add_argument('--fused_patch', type=str2bool, default='False',
                    help='l1_loss only: fused patch kernel instead of the full-frame warp')
     p.add_argument('--solve_f64', type=str2bool, default='False', help='carry the 8x8 DLT solve in f64')
+    p.add_argument('--step_graph', type=str2bool, default='False',
+                   help='capture the whole training step (convs, hot path, Adam) into one hipGraph and replay it')
     p.add_argument('--graph_tail', type=str2bool, default='False',
                    help='l1_loss only: DLT -> warp -> loss and their backward as one library call / one hipGraph launch')
     p.add_argument('--fresh_data_every', type=int, default=1, help='draw a new synthetic batch every N steps')
@@ -108,12 +110,21 @@ class TrainStep(object):
                 torch.distributed.broadcast(t.data, src=0)
         self.decay_steps = decay_steps_for(args.lr, args.min_lr)
         self.global_step = 0
-        self.averager = uh_dist.GradAverager(self.net, world)
+        # world == 1: no exchange step -> no flat buckets: autograd hands each parameter its gradient directly (no
+        # 137 MB zero fill + read-modify-write accumulation per step)
+        self.averager = uh_dist.GradAverager(self.net, world) if world > 1 else None
         kw = {}
+        self.step_graph = bool(getattr(args, 'step_graph', False)) and device.type == 'cuda' and world == 1
+        lr0 = args.lr
         if device.type == 'cuda':
             kw['fused'] = True
-        self.opt = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=args.lr,
+        if self.step_graph:
+            # whole-step hipGraph: Adam must not read host scalars at replay time -> capturable state, lr as a tensor
+            kw['capturable'] = True
+            lr0 = torch.tensor(float(args.lr), device=device)
+        self.opt = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr0,
                                     betas=(0.9, 0.999), eps=1e-8, **kw)
+        self._graph = None
         self.model_params = homography_model_params(
             mode=args.mode, batch_size=int(args.batch_size / world), patch_size=args.patch_size,
             img_h=args.img_h, img_w=args.img_w, loss_type=args.loss_type, use_batch_norm=args.use_batch_norm,
@@ -122,8 +133,61 @@ class TrainStep(object):
     def learning_rate(self):
         return staircase_lr(self.args.lr, self.global_step, self.decay_steps)
 
+    # ---- whole-step hipGraph (torch.cuda.CUDAGraph on ROCm) -----------------------------------------------
+    # One training step is ~150 launches (convs, epilogues, the hot-path kernels, fused Adam) with ~10 % of the step
+    # spent in launch gaps on an otherwise GPU-bound stream.  Shapes are static, so the step is captured ONCE into a
+    # hipGraph over static input buffers and replayed: one graph launch per step, no per-kernel launch latency.  The
+    # library's kernels are captured like any other stream work (they only enqueue on the current stream).
+    def _set_lr(self):
+        lr = self.learning_rate()
+        for g in self.opt.param_groups:
+            if torch.is_tensor(g['lr']):
+                g['lr'].fill_(lr)
+            else:
+                g['lr'] = lr
+
+    def _capture(self, batch):
+        self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                    # eager warm-up on a side stream (MIOpen find, allocator, Adam state)
+            for _ in range(3):
+                self._forward_backward_update(self._static)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_model = self._forward_backward_update(self._static)
+
+    def _zero_or_reset(self):
+        if self.averager is not None:
+            self.averager.reset()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+
+    def _forward_backward_update(self, batch):
+        self._zero_or_reset()
+        model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
+                                net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64)
+        model.loss.backward()
+        if self.averager is not None:
+            self.averager.finish()
+        self.opt.step()
+        return model
+
     def __call__(self, batch):
         """sess.run([apply_grad_opt, ...]) of the hot loop (:333-353): forward, backward, average, Adam."""
+        if self.step_graph:
+            self._set_lr()
+            if self._graph is None:
+                self._capture(batch)                     # includes 3 eager warm-up steps
+                self.global_step += 3
+            for k, v in batch.items():                   # new data lands in the static buffers the graph reads
+                if torch.is_tensor(v) and v.data_ptr() != self._static[k].data_ptr():
+                    self._static[k].copy_(v)
+            self._graph.replay()
+            self.global_step += 1
+            return self._graph_model                     # its tensors are the graph's static outputs
         if getattr(self.args, 'graph_tail', False) and self.device.type == 'cuda':
             # stream capture needs a real (non-NULL) stream: run the whole step on a private one
             if not hasattr(self, '_stream'):
@@ -139,12 +203,13 @@ class TrainStep(object):
         lr = self.learning_rate()
         for g in self.opt.param_groups:
             g['lr'] = lr
-        self.averager.reset()
+        self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
                                 graph_tail=getattr(self.args, 'graph_tail', False))
         model.loss.backward()
-        self.averager.finish()
+        if self.averager is not None:
+            self.averager.finish()
         self.opt.step()
         self.global_step += 1
         return model

@@ -35,11 +35,18 @@ homography_model_params = namedtuple('parameters',
 LOSS_TYPES = ('h_loss', 'rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss')
 
 
+_GAUSS_CACHE = {}
+
+
 def fspecial_gauss(size, sigma, device=None):
-    """MATLAB fspecial('gaussian') (homography_model.py:24-40); only used as the stored ssim_window."""
-    x, y = np.mgrid[-size // 2 + 1:size // 2 + 1, -size // 2 + 1:size // 2 + 1]
-    g = np.exp(-((x ** 2 + y ** 2) / (2.0 * sigma ** 2)))
-    return torch.tensor(g / g.sum(), dtype=torch.float32, device=device)
+    """MATLAB fspecial('gaussian') (homography_model.py:24-40); only used as the stored ssim_window.  Cached per
+    device: a host->device copy is not allowed while the step is being captured into a hipGraph."""
+    key = (size, sigma, str(device))
+    if key not in _GAUSS_CACHE:
+        x, y = np.mgrid[-size // 2 + 1:size // 2 + 1, -size // 2 + 1:size // 2 + 1]
+        g = np.exp(-((x ** 2 + y ** 2) / (2.0 * sigma ** 2)))
+        _GAUSS_CACHE[key] = torch.tensor(g / g.sum(), dtype=torch.float32, device=device)
+    return _GAUSS_CACHE[key]
 
 
 class VGGRegressor(nn.Module):
