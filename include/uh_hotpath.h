@@ -92,6 +92,12 @@ UH_API int uh_dlt_backward(const float* pts1, const float* h4p, const float* H,
 UH_API int uh_warp_forward(const float* U, const float* theta, float* out, float* condition,
                     int B, int H, int W, int C, int oh, int ow, uh_stream_t stream);
 
+/* Validation twin of uh_warp_forward: the literal op-for-op transcription (compiler IEEE division, integer cast and
+ * clamps, one pixel per thread, no staging).  Slow; exists so that tests can check the optimised kernel bit for bit on
+ * the GPU at full sizes.  Same arguments minus `condition`.                                                         */
+UH_API int uh_warp_forward_literal(const float* U, const float* theta, float* out,
+                            int B, int H, int W, int C, int oh, int ow, uh_stream_t stream);
+
 UH_API size_t uh_warp_backward_workspace_bytes(int B, int H, int W, int C, int oh, int ow);
 
 /* dTheta [B,9] = d loss/d theta given dOut [B,oh,ow,C].  dU (may be NULL) receives d loss/d U

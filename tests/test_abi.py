@@ -57,6 +57,35 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert lib.uh_warp_backward_workspace_bytes(0, 240, 320, 3, 240, 320) == 0
     assert b'UH_E_WORKSPACE' in lib.uh_error_string(-4)
     assert lib.uh_kernel_name(2) == b'warp_forward'
+    # entry points added after the first slice
+    assert lib.uh_warp_forward_literal(one, one, None, 1, 8, 8, 3, 8, 8, None) == -1
+    assert lib.uh_patch_losses_forward(one, one, one, None, one, one, 1 << 20, 2, 16, None) == -1   # h4p xor gt
+    assert lib.uh_patch_losses_forward(one, one, None, None, one, one, 1 << 20, 2, 2, None) == -2   # P < 3 (3x3 SSIM window)
+    assert lib.uh_patch_losses_forward(one, one, None, None, one, None, 0, 2, 16, None) == -4
+    assert lib.uh_patch_losses_workspace_bytes(64, 128) == 64 * 64 * 7 * 4
+    args13 = [one] * 13
+    assert lib.uh_prepare_inputs(*args13, 0, 8, 8, 4, None) == -2
+    assert lib.uh_prepare_inputs(*args13, 2, 8, 8, 16, None) == -2                                  # patch larger than frame
+    assert lib.uh_prepare_inputs(None, *args13[1:], 2, 8, 8, 4, None) == -1
+    assert lib.uh_bias_relu_forward(one, one, 100, 6, None) == -3                                    # C % 4 != 0
+    assert lib.uh_bias_relu_forward(one, one, 100, 96, None) == -3                                   # 1024 % C != 0
+    assert lib.uh_bias_relu_forward(one, None, 100, 64, None) == -1
+    assert lib.uh_bias_relu_backward(one, one, one, one, None, 0, 100, 64, None) == -4
+    assert lib.uh_bias_relu_pool_forward(one, one, one, 2, 7, 8, 64, None) == -2                     # odd height
+    assert lib.uh_bias_relu_pool_backward_workspace_bytes(2, 7, 8, 64) == 0
+    plan = C.c_void_p()
+    assert lib.uh_tail_create(C.byref(plan), 4, 60, 80, 3, 128, 0) == -2                             # patch larger than frame
+    assert lib.uh_tail_create(C.byref(plan), 4, 60, 80, 5, 32, 0) == -3
+    assert lib.uh_tail_create(C.byref(plan), 4, 60, 80, 3, 32, _lib.UH_TAIL_GRAPH) == 0 and plan.value
+    nb_full = lib.uh_tail_workspace_bytes(plan)
+    assert nb_full >= 2 * 4 * 60 * 80 * 3 * 4 and lib.uh_tail_warped_offset(plan) % 256 == 0
+    assert lib.uh_tail_run(plan, *([one] * 11), one, nb_full - 1, None) == -4
+    assert lib.uh_tail_run(plan, None, *([one] * 10), one, nb_full, None) == -1
+    lib.uh_tail_destroy(plan)
+    plan2 = C.c_void_p()
+    assert lib.uh_tail_create(C.byref(plan2), 4, 60, 80, 3, 32, _lib.UH_TAIL_FUSED_PATCH) == 0
+    assert lib.uh_tail_workspace_bytes(plan2) < 64 * 1024 and lib.uh_tail_warped_offset(plan2) == C.c_size_t(-1).value
+    lib.uh_tail_destroy(plan2)
 
 
 def test_product_path_refuses_cpu_tensors(uh_lib_path):

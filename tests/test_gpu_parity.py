@@ -192,6 +192,28 @@ def test_warp_forward_staged_and_gather_paths(ops, dev, C):
         assert relerr(got[k], dth[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize('cfg', [(32, 240, 320, 45), (8, 480, 640, 64)])
+def test_warp_forward_lean_equals_literal_at_full_size(ops, dev, cfg):
+    """Full BASELINE sizes, where the CPU oracle is too slow: the optimised kernel (shared-reciprocal division, float
+    clips, f32 offsets, LDS staging / gather per wave) against the literal transcription running on the GPU with the
+    compiler's IEEE division -- bit for bit, on the benchmark's theta law plus a far-field tail (2.5M-2.5M samples)."""
+    B, H, W, rho = cfg
+    P = 128
+    g = torch.Generator(device='cpu').manual_seed(B)
+    x0 = torch.randint(rho, W - rho - P + 1, (B,), generator=g); y0 = torch.randint(rho, H - rho - P + 1, (B,), generator=g)
+    pts1 = torch.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).float().to(dev)
+    h4p = (torch.randint(-rho, rho + 1, (B, 8), generator=g).float() + 2.0 * torch.randn(B, 8, generator=g)).to(dev)
+    _, theta = ops.solve_dlt(pts1, h4p, img_w=W, img_h=H)
+    theta = theta.detach().clone()
+    theta[0] = torch.tensor([[1e5, 0, 0], [0, 1e5, 0], [0, 0, 1e-5]], device=dev)      # |x| ~ 1e12: int32 overflow rule
+    theta[1] = torch.tensor([[1, 0, 0], [0, 1, 0], [0.7, 0.6, 0.01]], device=dev)      # t changes sign inside the frame
+    U = torch.randn(B, H, W, 3, generator=g).to(dev)
+    out, _ = ops.transformer(U, theta, (H, W), with_condition=False)
+    lit = ops.transformer_literal(U, theta, (H, W))
+    same = (out == lit) | (torch.isnan(out) & torch.isnan(lit))
+    assert bool(same.all()), int((~same).sum())
+
+
 def test_warp_forward_large_image_offsets(ops, dev):
     """An image of more than 2^24 bytes takes the integer-offset path (offsets no longer exact in f32)."""
     rs = np.random.RandomState(5)

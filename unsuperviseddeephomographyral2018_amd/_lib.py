@@ -26,6 +26,7 @@ SIGNATURES = {
     'uh_dlt_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _u, _p]),
     'uh_dlt_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _u, _p]),
     'uh_warp_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'uh_warp_forward_literal': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'uh_warp_backward_workspace_bytes': (_z, [_i, _i, _i, _i, _i, _i]),
     'uh_warp_backward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),
     'uh_gray_patch_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -338,6 +338,28 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Literal forward (validation only): one pixel per thread, the op-for-op transcription make_sample()/blend() with
+// the compiler's IEEE division, x86-style integer cast and integer clamps, plain global loads.  It exists so that the
+// lean path above (shared-reciprocal division, float-domain clips, f32 offsets, LDS staging) can be checked BIT FOR
+// BIT on the GPU at full sizes and over millions of thetas' worth of samples (tests/test_gpu_parity.py).
+template <int C>
+__global__ __launch_bounds__(256) void warp_forward_literal_kernel(const float* __restrict__ U, const float* __restrict__ theta,
+                                                                   float* __restrict__ out, int H, int W, int oh, int ow) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= oh * ow) return;
+    const int row = p / ow, col = p - row * ow;
+    const Theta th = load_theta(theta, b);
+    const Sample s = make_sample(th, lin_at(lin_step(ow), col), lin_at(lin_step(oh), row), W, H);
+    const float* Ub = U + (size_t)b * H * W * C;
+    float* Ob = out + ((size_t)b * oh * ow + p) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        Ob[c] = blend(s, Ub[((size_t)s.y0 * W + s.x0) * C + c], Ub[((size_t)s.y1 * W + s.x0) * C + c],
+                      Ub[((size_t)s.y0 * W + s.x1) * C + c], Ub[((size_t)s.y1 * W + s.x1) * C + c]);
+}
+
 // Deterministic finish: dTheta[b][j] = sum over the image's tiles, accumulated in f64, fixed order.
 // One wave per image.  The image's partials are `tiles*9` contiguous floats; lane l < 63 walks them
 // with stride 63 (= 7*9), so its accumulator index j = l % 9 never changes and every load instruction
@@ -456,6 +478,22 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
         const TileGeom g = tile_geom(oh, ow);
         launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel, dim3((B + 3) / 4), dim3(256), s,
                      (const float*)partial, dTheta, g.tiles, B);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int uh_warp_forward_literal(const float* U, const float* theta, float* out, int B, int H, int W, int C,
+                                       int oh, int ow, uh_stream_t stream) {
+    if (!U || !theta || !out) return UH_E_NULL;
+    if (int e = check_warp_args(B, H, W, C, oh, ow)) return e;
+    if (B > 65535) return UH_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((oh * ow + 255) / 256, B), block(256);
+    switch (C) {
+        case 1: hipLaunchKernelGGL(warp_forward_literal_kernel<1>, grid, block, 0, s, U, theta, out, H, W, oh, ow); break;
+        case 2: hipLaunchKernelGGL(warp_forward_literal_kernel<2>, grid, block, 0, s, U, theta, out, H, W, oh, ow); break;
+        case 3: hipLaunchKernelGGL(warp_forward_literal_kernel<3>, grid, block, 0, s, U, theta, out, H, W, oh, ow); break;
+        default: hipLaunchKernelGGL(warp_forward_literal_kernel<4>, grid, block, 0, s, U, theta, out, H, W, oh, ow); break;
     }
     return (int)hipGetLastError();
 }

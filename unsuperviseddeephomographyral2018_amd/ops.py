@@ -163,6 +163,18 @@ def transformer(U, theta, out_size, name='SpatialTransformer', with_condition=Tr
     return res, None
 
 
+def transformer_literal(U, theta, out_size):
+    """Validation twin of transformer(): literal op order, compiler division (uh_warp_forward_literal).  No gradient."""
+    lib = _lib.load()
+    U = _f32(U.detach(), 'U')
+    B, H, W, Cc = U.shape
+    theta = _f32(theta.detach(), 'theta').reshape(-1, 9)
+    out = torch.empty((B, int(out_size[0]), int(out_size[1]), Cc), dtype=torch.float32, device=U.device)
+    _lib.check(lib.uh_warp_forward_literal(_ptr(U), _ptr(theta), _ptr(out), B, H, W, Cc, int(out_size[0]),
+                                           int(out_size[1]), _stream()), 'uh_warp_forward_literal')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 class _GrayPatch(torch.autograd.Function):
     @staticmethod
