@@ -118,7 +118,12 @@ def test_end_to_end_gradient_vs_cpu_op_graph(pkg, dev):
     assert float((pred_I2 - m.pred_I2.detach().cpu()).abs().max()) < 2e-3
     for (n, pc), pg in zip(net.named_parameters(), net_gpu.parameters()):
         rel = float((pc.grad - pg.grad.cpu()).abs().max() / pc.grad.abs().max().clamp_min(1e-30))
-        assert rel < 2e-3, (n, rel)
+        # Layers after the last max-pool (convs.6, convs.7, fc1, fc2) see the hot path's gradient through smooth ops only:
+        # tight.  Below a max-pool the comparison is at the mercy of near-tied pooling winners: a 1e-7 difference between the
+        # CPU and MIOpen conv outputs (MIOpen may pick split-K atomic solvers depending on what ran earlier in the process)
+        # flips a few winners on these smooth inputs and moves those gradients by ~1e-3..1e-2.
+        tight = n.split('.')[0] in ('fc1', 'fc2') or n.startswith(('convs.6', 'convs.7'))
+        assert rel < (2e-3 if tight else 5e-2), (n, rel)
 
 
 def test_train_step_overfits_fixed_batch(pkg, dev):
