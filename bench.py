@@ -50,8 +50,8 @@ def parse():
     ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object); 1: time the warp kernels; 2: time every library kernel')
     ap.add_argument('--cpu_baseline', type=int, default=1)
     ap.add_argument('--north_star', type=int, default=1, help='0: skip the extra warp-only measurement at batch 128')
-    ap.add_argument('--cpu_sample_pairs', type=int, default=8)
-    ap.add_argument('--cpu_sample_steps', type=int, default=2)
+    ap.add_argument('--cpu_sample_pairs', type=int, default=64, help='CPU leg: batch size (default = the GPU batch)')
+    ap.add_argument('--cpu_sample_steps', type=int, default=4, help='CPU leg: timed steps after one warm-up step')
     ap.add_argument('--cpu_threads', type=int, default=32, help='host threads for the CPU leg (capped at nproc)')
     return ap.parse_args()
 

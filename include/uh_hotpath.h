@@ -112,7 +112,7 @@ UH_API int uh_warp_backward(const float* U, const float* theta, const float* dOu
  * pred[k,i] = mean_c warped[k, patch_idx[k,i], c]                                                  */
 UH_API int uh_gray_patch_forward(const float* warped, const int* patch_idx, float* pred,
                           int B, int H, int W, int C, int PP, uh_stream_t stream);
-/* dWarped [B,H,W,C] is fully overwritten: zero + scatter-add of dPred/C (duplicates allowed).       */
+/* dWarped [B,H,W,C] is fully overwritten: scatter-add of dPred/C into a zero frame (duplicates sum; any index set). */
 UH_API int uh_gray_patch_backward(const float* dPred, const int* patch_idx, float* dWarped,
                            int B, int H, int W, int C, int PP, uh_stream_t stream);
 

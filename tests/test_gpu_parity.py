@@ -329,6 +329,42 @@ def test_gray_patch_duplicate_indices(ops, dev):
     assert np.count_nonzero(gr) == 6
 
 
+@pytest.mark.parametrize('case', ['rect', 'rect_wrapping_row', 'rect_with_swaps_and_dups', 'random', 'non_square'])
+def test_gray_patch_backward_index_sets(ops, dev, case):
+    """uh_gray_patch_backward = scatter-ADD of dPred/C into a zero frame for ANY index set (tf.gather's gradient).  The
+    kernel pair (dense rectangle write + atomic fix-up of the entries that are not at their rectangle position) must give
+    the same frame as a NumPy np.add.at for: the dataloader's rectangle, a rectangle whose rows run past the right edge,
+    a rectangle with a few swapped / duplicated entries, fully random indices, and PP that is not a square."""
+    rs = np.random.RandomState(hash(case) % 1000)
+    B, H, W, C, P = 3, 20, 28, 3, 6
+    PP = P * P
+    u = np.arange(P)
+    x0 = np.array([3, 10, 20]); y0 = np.array([2, 9, 13])
+    if case == 'rect_wrapping_row':
+        x0 = np.array([25, 26, 24])                         # x0 + P > W: (y0+v)*W + x0 + u spills into the next row
+    idx = ((u[None, :, None] + y0[:, None, None]) * W + (u[None, None, :] + x0[:, None, None])).reshape(B, PP)
+    if case == 'rect_with_swaps_and_dups':
+        idx[0, [3, 17]] = idx[0, [17, 3]]; idx[1, 5] = idx[1, 6]; idx[2, 0] = idx[2, 35]
+    elif case == 'random':
+        idx = rs.randint(0, H * W, (B, PP))
+    elif case == 'non_square':
+        PP = 30; idx = idx[:, :PP]
+    idx = np.clip(idx, 0, H * W - 1).astype(np.int32)
+    dP = rs.randn(B, PP).astype(np.float32)
+    from unsuperviseddeephomographyral2018_amd import _lib
+    import ctypes as C_
+    lib = _lib.load()
+    dW = torch.full((B, H, W, C), 7.0, device=dev)          # must be fully overwritten
+    p = lambda t: C_.c_void_p(t.data_ptr())
+    tdP, tidx = T(dP, dev), T(idx, dev)
+    _lib.check(lib.uh_gray_patch_backward(p(tdP), p(tidx), p(dW), B, H, W, C, PP,
+                                          C_.c_void_p(torch.cuda.current_stream().cuda_stream)), 'uh_gray_patch_backward')
+    ref = np.zeros((B, H * W, C), np.float64)
+    for k in range(B):
+        np.add.at(ref[k], idx[k], (dP[k].astype(np.float64) / C)[:, None])
+    assert np.abs(dW.cpu().numpy().reshape(B, H * W, C) - ref).max() <= 1e-6
+
+
 # ---------------------------------------------------------------------------------------------- chain
 def chain_unfused(ops, I, I2, pts1, h4p, idx, P, W, H, f64=False):
     Hm, theta = ops.solve_dlt(pts1, h4p, img_w=W, img_h=H, solve_f64=f64)

@@ -29,17 +29,58 @@ __global__ __launch_bounds__(256) void gray_patch_forward_kernel(const float* __
     }
 }
 
+// Backward of the gather = scatter-add of dPred/C into a zero frame (duplicates sum, like tf.gather's gradient).
+// The dataloader's indices are a P x P rectangle, (v + y0)*W + (u + x0): memset + 3 float atomics per patch pixel
+// (43 us at B=64) is a poor way to write a mostly-zero 59 MB frame.  Two kernels, no memset, still fully general:
+//   dense  : every frame pixel is written exactly once -- the value of the patch entry that SHOULD sit there if the
+//            patch is the rectangle anchored at patch_idx[k,0] (and whose stored index confirms it), else 0;
+//   fix-up : every patch entry whose stored index is NOT its rectangle position (arbitrary gathers, duplicates,
+//            PP not a square -> P = 0 -> every entry) is added atomically on top.  For rectangles it adds nothing.
 template <int C>
-__global__ __launch_bounds__(256) void gray_patch_backward_kernel(const float* __restrict__ dPred,
-                                                                  const int* __restrict__ patch_idx,
-                                                                  float* __restrict__ dWarped, int HW, int PP, int B) {
+__global__ __launch_bounds__(256) void gray_patch_backward_dense_kernel(const float* __restrict__ dPred,
+                                                                        const int* __restrict__ patch_idx,
+                                                                        float* __restrict__ dWarped, int HW, int W, int P,
+                                                                        int PP) {
+    const int k = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int* idx = patch_idx + (size_t)k * PP;
+    const int o = idx[0];                                    // uniform -> scalar load
+    const int y0 = o / W, x0 = o - y0 * W;
+    const int y = p / W, x = p - y * W;
+    const int u = x - x0, v = y - y0;
+    float g = 0.f;
+    if (u >= 0 && u < P && v >= 0 && v < P) {
+        const int e = v * P + u;
+        if (idx[e] == p) g = dPred[(size_t)k * PP + e] / (float)C;
+    }
+    float* q = dWarped + ((size_t)k * HW + p) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) q[c] = g;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void gray_patch_backward_fixup_kernel(const float* __restrict__ dPred,
+                                                                        const int* __restrict__ patch_idx,
+                                                                        float* __restrict__ dWarped, int HW, int W, int H,
+                                                                        int P, int PP, int B) {
     const size_t n = (size_t)B * PP;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int k = (int)(i / PP);
-        float* p = dWarped + ((size_t)k * HW + patch_idx[i]) * C;
-        const float g = dPred[i] / (float)C;
+        const int k = (int)(i / PP), e = (int)(i - (size_t)k * PP);
+        const int t = patch_idx[i];
+        bool direct = false;
+        if (P > 0) {
+            const int o = patch_idx[(size_t)k * PP];
+            const int y0 = o / W, x0 = o - y0 * W;
+            const int v = e / P, u = e - v * P;
+            direct = (x0 + u < W) && (y0 + v < H) && t == (y0 + v) * W + (x0 + u);
+        }
+        if (!direct) {
+            float* q = dWarped + ((size_t)k * HW + t) * C;
+            const float g = dPred[i] / (float)C;
 #pragma unroll
-        for (int c = 0; c < C; ++c) atomicAdd(p + c, g);
+            for (int c = 0; c < C; ++c) atomicAdd(q + c, g);
+        }
     }
 }
 
@@ -207,17 +248,24 @@ extern "C" int uh_gray_patch_forward(const float* warped, const int* patch_idx, 
 extern "C" int uh_gray_patch_backward(const float* dPred, const int* patch_idx, float* dWarped, int B, int H, int W,
                                       int C, int PP, uh_stream_t stream) {
     if (int e = check_gray(dPred, patch_idx, dWarped, B, H, W, C, PP)) return e;
+    if (B > 65535) return UH_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(UH_K_GRAY_BWD, s);
-    hipError_t e = hipMemsetAsync(dWarped, 0, (size_t)B * H * W * C * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-    const unsigned g = grid_for((size_t)B * PP);
+    int P = 0;
+    for (int r = 1; (long long)r * r <= PP; ++r) if (r * r == PP) P = r;          // PP not a square: P = 0 (all entries via fix-up)
+    const dim3 gd((H * W + 255) / 256, B);
+    const unsigned gf = grid_for((size_t)B * PP);
+#define UH_GPB(CC) do { \
+        hipLaunchKernelGGL(gray_patch_backward_dense_kernel<CC>, gd, dim3(256), 0, s, dPred, patch_idx, dWarped, H * W, W, P, PP); \
+        hipLaunchKernelGGL(gray_patch_backward_fixup_kernel<CC>, dim3(gf), dim3(256), 0, s, dPred, patch_idx, dWarped, H * W, W, H, P, PP, B); \
+    } while (0)
     switch (C) {
-        case 1: hipLaunchKernelGGL(gray_patch_backward_kernel<1>, dim3(g), dim3(256), 0, s, dPred, patch_idx, dWarped, H * W, PP, B); break;
-        case 2: hipLaunchKernelGGL(gray_patch_backward_kernel<2>, dim3(g), dim3(256), 0, s, dPred, patch_idx, dWarped, H * W, PP, B); break;
-        case 3: hipLaunchKernelGGL(gray_patch_backward_kernel<3>, dim3(g), dim3(256), 0, s, dPred, patch_idx, dWarped, H * W, PP, B); break;
-        default: hipLaunchKernelGGL(gray_patch_backward_kernel<4>, dim3(g), dim3(256), 0, s, dPred, patch_idx, dWarped, H * W, PP, B); break;
+        case 1: UH_GPB(1); break;
+        case 2: UH_GPB(2); break;
+        case 3: UH_GPB(3); break;
+        default: UH_GPB(4); break;
     }
+#undef UH_GPB
     return (int)hipGetLastError();
 }
 
