@@ -45,8 +45,13 @@ namespace uh {
 #endif
 constexpr int TW = UH_WARP_TW;          // wave tile width (pixels)
 constexpr int WY = 64 / TW;             // rows a wave covers per step
-constexpr int STEPS = UH_WARP_STEPS;    // pixels per lane
-constexpr int TH = WY * STEPS;          // wave tile height
+#ifndef UH_WARP_STEPS_BWD
+#define UH_WARP_STEPS_BWD UH_WARP_STEPS
+#endif
+constexpr int STEPS = UH_WARP_STEPS;    // pixels per lane (forward)
+constexpr int TH = WY * STEPS;          // wave tile height (forward)
+constexpr int STEPS_B = UH_WARP_STEPS_BWD;   // pixels per lane (backward)
+constexpr int TH_B = WY * STEPS_B;           // wave tile height (backward)
 constexpr int NWAVE = 4;                // waves per block, side by side in x: block tile = (4*TW) x TH
 constexpr int LDS_PER_WAVE = UH_WARP_LDS_PER_WAVE;
 constexpr bool STAGE_FWD = UH_WARP_STAGE_FWD != 0, STAGE_BWD = UH_WARP_STAGE_BWD != 0;
@@ -54,10 +59,10 @@ static_assert(TW * WY == 64, "UH_WARP_TW must divide 64");
 static_assert(LDS_PER_WAVE % 1024 == 0 && LDS_PER_WAVE <= 16384, "LDS slice: multiple of 1 KiB, <= 16 KiB");
 
 struct TileGeom { int tiles_x, tiles_y, tiles; };
-static inline TileGeom tile_geom(int oh, int ow) {
+static inline TileGeom tile_geom(int oh, int ow, int th = TH) {
     TileGeom g;
     g.tiles_x = (ow + NWAVE * TW - 1) / (NWAVE * TW);
-    g.tiles_y = (oh + TH - 1) / TH;
+    g.tiles_y = (oh + th - 1) / th;
     g.tiles = g.tiles_x * g.tiles_y;
     return g;
 }
@@ -81,13 +86,13 @@ struct Rect {
     float pitch, nbase;  // pitch in bytes; nbase = -(by0*pitch + bx0*pixB)
     bool fits;
 };
-template <int C>
-__device__ __forceinline__ Rect wave_rect(const Coord (&c)[STEPS]) {
+template <int C, int N>
+__device__ __forceinline__ Rect wave_rect(const Coord (&c)[N]) {
     // the clipped corners are exact non-negative integers held in f32: their bit patterns order like integers
     int mnx = __float_as_int(c[0].x0f), mxx = __float_as_int(c[0].x1f);
     int mny = __float_as_int(c[0].y0f), mxy = __float_as_int(c[0].y1f);
 #pragma unroll
-    for (int k = 1; k < STEPS; ++k) {
+    for (int k = 1; k < N; ++k) {
         mnx = min(mnx, __float_as_int(c[k].x0f)); mxx = max(mxx, __float_as_int(c[k].x1f));
         mny = min(mny, __float_as_int(c[k].y0f)); mxy = max(mxy, __float_as_int(c[k].y1f));
     }
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256) void warp_forward_kernel(
     for (int k = 0; k < STEPS; ++k) c[k] = make_coord(th, A0, A3, A6, -1.0f + sy * (rowf0 + (float)(k * WY)), g);
     Rect r;
     r.fits = false;
-    if constexpr (STAGE_FWD) r = wave_rect<C>(c);
+    if constexpr (STAGE_FWD) r = wave_rect<C, STEPS>(c);
 
     Pix<C> Ia[STEPS], Ib[STEPS], Ic[STEPS], Id[STEPS];
     if (STAGE_FWD && r.fits) {                                          // wave-uniform
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
     const int b = v / tiles, tile = v - b * tiles;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int col = (tx * NWAVE + wave) * TW + (lane & (TW - 1));
-    const int row0 = ty * TH + (lane / TW);                              // this lane's first row
+    const int row0 = ty * TH_B + (lane / TW);                              // this lane's first row
     float acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = 0.f;
@@ -256,49 +261,26 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
         const unsigned orow = (unsigned)(ow * C * 4);
 
         const float rowf0 = (float)row0;                                 // (float)(row0 + k*WY) == rowf0 + k*WY exactly
-        Coord c[STEPS];
-        Pix<C> G[STEPS];
-        float gy[STEPS];
+        Coord c[STEPS_B];
+        Pix<C> G[STEPS_B];
+        float gy[STEPS_B];
         // lanes past the right/bottom edge read dOut out of range (rows >= oh: offset >= num_records; columns
         // >= ow: offset 2^31) -> the buffer unit returns 0 -> they add exactly 0 to dTheta
         unsigned voff = col_ok ? (unsigned)row0 * orow + (unsigned)col * (C * 4) : 0x80000000u;
 #pragma unroll
-        for (int k = 0; k < STEPS; ++k) {
+        for (int k = 0; k < STEPS_B; ++k) {
             gy[k] = -1.0f + sy * (rowf0 + (float)(k * WY));
             G[k] = buf_load<C>(rg, voff, 0);
             voff += (unsigned)WY * orow;
             c[k] = make_coord(th, A0, A3, A6, gy[k], g);
         }
-        Rect r;
-        r.fits = false;
-        if constexpr (STAGE_BWD) r = wave_rect<C>(c);
-        Pix<C> Ia[STEPS], Ib[STEPS], Ic[STEPS], Id[STEPS];
-        if (STAGE_BWD && r.fits) {                                      // wave-uniform
-            stage_rect<C>(rin, lds, lane, r, g.rowBi);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int k = 0; k < STEPS; ++k) {
-                const TapOff o = staged_offsets(c[k], r.pitch, g.pixB, r.nbase);
-                Ia[k] = lds_load<C>(lds, o.oa); Ib[k] = lds_load<C>(lds, o.ob);
-                Ic[k] = lds_load<C>(lds, o.oc); Id[k] = lds_load<C>(lds, o.od);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < STEPS; ++k) {
-                const TapOff o = global_offsets<SMALL>(c[k], g);
-                Ia[k] = buf_load<C>(rin, o.oa, 0); Ib[k] = buf_load<C>(rin, o.ob, 0);
-                Ic[k] = buf_load<C>(rin, o.oc, 0); Id[k] = buf_load<C>(rin, o.od, 0);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < STEPS; ++k) {
+        // one pixel's contribution to the nine sums (and, optionally, to dU)
+        auto accumulate = [&](int k, const Pix<C>& Ia, const Pix<C>& Ib, const Pix<C>& Ic, const Pix<C>& Id) {
             float dx = 0.f, dy = 0.f;
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
-                const float ex = fmaf(c[k].ay1, Ic[k].v[ch] - Ia[k].v[ch], c[k].ay0 * (Id[k].v[ch] - Ib[k].v[ch]));
-                const float ey = fmaf(c[k].ax1, Ib[k].v[ch] - Ia[k].v[ch], c[k].ax0 * (Id[k].v[ch] - Ic[k].v[ch]));
+                const float ex = fmaf(c[k].ay1, Ic.v[ch] - Ia.v[ch], c[k].ay0 * (Id.v[ch] - Ib.v[ch]));
+                const float ey = fmaf(c[k].ax1, Ib.v[ch] - Ia.v[ch], c[k].ax0 * (Id.v[ch] - Ic.v[ch]));
                 dx = fmaf(G[k].v[ch], ex, dx);
                 dy = fmaf(G[k].v[ch], ey, dy);
             }
@@ -320,6 +302,34 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
                     atomicAdd(dUb + o.od / 4 + ch, wd * G[k].v[ch]);
                 }
             }
+        };
+        Rect r;
+        r.fits = false;
+        if constexpr (STAGE_BWD) r = wave_rect<C, STEPS_B>(c);
+        if (STAGE_BWD && r.fits) {                                      // wave-uniform
+            stage_rect<C>(rin, lds, lane, r, g.rowBi);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // one pixel at a time (LDS latency is short): only 4 taps live at once keeps the kernel under 96 VGPRs
+#pragma unroll
+            for (int k = 0; k < STEPS_B; ++k) {
+                const TapOff o = staged_offsets(c[k], r.pitch, g.pixB, r.nbase);
+                const Pix<C> Ia = lds_load<C>(lds, o.oa), Ib = lds_load<C>(lds, o.ob);
+                const Pix<C> Ic = lds_load<C>(lds, o.oc), Id = lds_load<C>(lds, o.od);
+                accumulate(k, Ia, Ib, Ic, Id);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            Pix<C> Ia[STEPS_B], Ib[STEPS_B], Ic[STEPS_B], Id[STEPS_B];         // all 16 gathers in flight before the first use
+#pragma unroll
+            for (int k = 0; k < STEPS_B; ++k) {
+                const TapOff o = global_offsets<SMALL>(c[k], g);
+                Ia[k] = buf_load<C>(rin, o.oa, 0); Ib[k] = buf_load<C>(rin, o.ob, 0);
+                Ic[k] = buf_load<C>(rin, o.oc, 0); Id[k] = buf_load<C>(rin, o.od, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < STEPS_B; ++k) accumulate(k, Ia[k], Ib[k], Ic[k], Id[k]);
         }
     }
     // block reduction: DPP inside rows of 16 lanes, the 16 row sums of the block meet in LDS (fixed order)
@@ -435,14 +445,14 @@ extern "C" int uh_warp_forward(const float* U, const float* theta, float* out, f
 
 extern "C" size_t uh_warp_backward_workspace_bytes(int B, int H, int W, int C, int oh, int ow) {
     if (check_warp_args(B, H, W, C, oh, ow)) return 0;
-    const TileGeom g = tile_geom(oh, ow);
+    const TileGeom g = tile_geom(oh, ow, TH_B);
     return (size_t)B * g.tiles * 9 * sizeof(float);
 }
 
 template <int C>
 static void launch_bwd(const float* U, const float* theta, const float* dOut, float* partial, float* dU, int B,
                        int H, int W, int oh, int ow, hipStream_t s) {
-    const TileGeom g = tile_geom(oh, ow);
+    const TileGeom g = tile_geom(oh, ow, TH_B);
     const unsigned nblk = (unsigned)B * g.tiles;
     const bool sm = small_image(H, W, C);
 #define UH_BWD(DU, SM) launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, DU, SM>, dim3(nblk), dim3(256), s, U, \
@@ -475,7 +485,7 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
         if (e != hipSuccess) return (int)e;
     }
     {
-        const TileGeom g = tile_geom(oh, ow);
+        const TileGeom g = tile_geom(oh, ow, TH_B);
         launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel, dim3((B + 3) / 4), dim3(256), s,
                      (const float*)partial, dTheta, g.tiles, B);
     }
