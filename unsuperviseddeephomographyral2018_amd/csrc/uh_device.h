@@ -93,37 +93,38 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
 }
 
-template <int C>
+// AUX = cache-policy bits of the buffer instruction (0 = default; 2 = nt, "non-temporal": streamed once)
+template <int C, int AUX = 0>
 __device__ __forceinline__ Pix<C> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     Pix<C> p;
     if constexpr (C == 1) {
-        p.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+        p.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
     } else if constexpr (C == 2) {
-        u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
         p.v[0] = __uint_as_float(t.x); p.v[1] = __uint_as_float(t.y);
     } else if constexpr (C == 3) {
-        u32x3_t t = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0);
+        u32x3_t t = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, AUX);
         p.v[0] = __uint_as_float(t.x); p.v[1] = __uint_as_float(t.y); p.v[2] = __uint_as_float(t.z);
     } else {
-        u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
         p.v[0] = __uint_as_float(t.x); p.v[1] = __uint_as_float(t.y); p.v[2] = __uint_as_float(t.z);
         p.v[3] = __uint_as_float(t.w);
     }
     return p;
 }
 
-template <int C>
+template <int C, int AUX = 0>
 __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const Pix<C>& p) {
     if constexpr (C == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p.v[0]), r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p.v[0]), r, voff, soff, AUX);
     } else if constexpr (C == 2) {
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(p.v[0]), __float_as_uint(p.v[1])}, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(p.v[0]), __float_as_uint(p.v[1])}, r, voff, soff, AUX);
     } else if constexpr (C == 3) {
         __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{__float_as_uint(p.v[0]), __float_as_uint(p.v[1]),
-                                                      __float_as_uint(p.v[2])}, r, voff, soff, 0);
+                                                      __float_as_uint(p.v[2])}, r, voff, soff, AUX);
     } else {
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(p.v[0]), __float_as_uint(p.v[1]),
-                                                       __float_as_uint(p.v[2]), __float_as_uint(p.v[3])}, r, voff, soff, 0);
+                                                       __float_as_uint(p.v[2]), __float_as_uint(p.v[3])}, r, voff, soff, AUX);
     }
 }
 

@@ -45,6 +45,12 @@ namespace uh {
 #endif
 constexpr int TW = UH_WARP_TW;          // wave tile width (pixels)
 constexpr int WY = 64 / TW;             // rows a wave covers per step
+#ifndef UH_WARP_STORE_AUX
+#define UH_WARP_STORE_AUX 0       // cache policy of the forward's `out` stores: 0 default, 2 = nt (non-temporal)
+#endif
+#ifndef UH_WARP_GLOAD_AUX
+#define UH_WARP_GLOAD_AUX 0       // cache policy of the backward's dOut loads
+#endif
 #ifndef UH_WARP_STEPS_BWD
 #define UH_WARP_STEPS_BWD UH_WARP_STEPS
 #endif
@@ -208,9 +214,9 @@ __global__ __launch_bounds__(256) void warp_forward_kernel(
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) o.v[ch] = blend4(wa, wb, wc, wd, Ia[k].v[ch], Ib[k].v[ch], Ic[k].v[ch], Id[k].v[ch]);
 #ifdef UH_DBG_NO_STORE            // developer A/B switch only: keeps the math alive, never stores
-        buf_store<C>(rout, o.v[0] != 12345.678f ? 0x80000000u : voff, 0, o);
+        buf_store<C, UH_WARP_STORE_AUX>(rout, o.v[0] != 12345.678f ? 0x80000000u : voff, 0, o);
 #else
-        buf_store<C>(rout, voff, 0, o);
+        buf_store<C, UH_WARP_STORE_AUX>(rout, voff, 0, o);
 #endif
         if (COND) cnt += (col_ok && row0 + k * WY < oh && fabsf(c[k].t) > 1e-7f) ? 1.f : 0.f;   // (:235)
         voff += (unsigned)WY * orow;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
 #pragma unroll
         for (int k = 0; k < STEPS_B; ++k) {
             gy[k] = -1.0f + sy * (rowf0 + (float)(k * WY));
-            G[k] = buf_load<C>(rg, voff, 0);
+            G[k] = buf_load<C, UH_WARP_GLOAD_AUX>(rg, voff, 0);
             voff += (unsigned)WY * orow;
             c[k] = make_coord(th, A0, A3, A6, gy[k], g);
         }
