@@ -106,3 +106,16 @@ def test_product_package_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback: with the shared library absent, loading (and therefore every op) raises, it never computes."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from unsuperviseddeephomographyral2018_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.UHError as e:\n    print('RAISED', 'no CPU fallback' in str(e).replace('There is no', 'no'))\n"
+            "else:\n    print('LOADED')\n") % ROOT
+    env = dict(os.environ, UH_LIB_PATH=str(tmp_path / 'libuh_missing.so'))
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    assert 'RAISED True' in out.stdout, out.stdout + out.stderr

@@ -263,3 +263,24 @@ def test_conv_bias_relu_epilogue_equals_torch(pkg, dev):
         # below a max-pool a near-tied winner may flip between the two forward passes (see the e2e test): loose there
         tight = n.split('.')[0] in ('fc1', 'fc2') or n.startswith(('convs.6', 'convs.7'))
         assert (ga - gb).abs().max() <= (1e-3 if tight else 5e-2) * max(1e-6, float(gb.abs().max())), n
+
+
+def test_whole_step_hipgraph_trains(pkg, dev):
+    """--step_graph: the whole training step (convs, epilogues, hot path, capturable fused Adam) captured into one
+    hipGraph and replayed.  The replayed steps must keep training (loss on a fixed batch goes down) and new batch data
+    copied into the static buffers must be what the graph consumes."""
+    hm, synthetic, drv = pkg
+    args = drv.build_parser().parse_args(['--batch_size', str(B), '--img_h', str(H), '--img_w', str(W), '--patch_size', str(P),
+                                          '--rho', str(RHO), '--loss_type', 'l1_loss', '--step_graph', 'True', '--lr', '1e-4'])
+    torch.manual_seed(0)
+    step = drv.TrainStep(args, dev, 1)
+    batch = synthetic.make_batch(B, H, W, P, RHO, seed=21, device=dev)
+    losses = []
+    for _ in range(40):
+        m = step(batch)
+        losses.append(float(m.l1_loss.detach()))
+    assert step._graph is not None and step.global_step == 43          # 3 eager warm-up steps + 40 replays
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
+    other = synthetic.make_batch(B, H, W, P, RHO, seed=22, device=dev)
+    m = step(other)
+    assert torch.equal(step._static['I_aug'], other['I_aug']) and torch.equal(m.I, step._static['I_aug'])

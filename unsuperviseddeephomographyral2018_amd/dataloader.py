@@ -85,9 +85,12 @@ def prepare_inputs(I_u8, I_prime_u8, pts1, patch_size, aug=None, mean=MEAN_I, st
         if tuple(aug.shape) != (B, 2, 5):
             raise _lib.UHError('aug must be [B,2,5]')
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    out = dict(I_aug=f(B, H, W, 3), I_prime_aug=f(B, H, W, 3), I1=f(B, P, P, 1), I2=f(B, P, P, 1),
-               I1_aug=f(B, P, P, 1), I2_aug=f(B, P, P, 1),
-               patch_indices=torch.empty((B, P * P), dtype=torch.int32, device=dev), pts1=pts1)
+    # the patch tensors are zero-filled: the kernel writes a patch entry only where the patch lies inside the frame
+    # (gen_synthetic_data.py:42-53 guarantees it does); a patch sticking out leaves zeros / index 0, never garbage
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    out = dict(I_aug=f(B, H, W, 3), I_prime_aug=f(B, H, W, 3), I1=z(B, P, P, 1), I2=z(B, P, P, 1),
+               I1_aug=z(B, P, P, 1), I2_aug=z(B, P, P, 1),
+               patch_indices=torch.zeros((B, P * P), dtype=torch.int32, device=dev), pts1=pts1)
     m = (C.c_float * 3)(*mean); s = (C.c_float * 3)(*std)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     _lib.check(lib.uh_prepare_inputs(p(I_u8), p(I_prime_u8), p(aug), p(pts1), m, s, p(out['I_aug']), p(out['I_prime_aug']),
