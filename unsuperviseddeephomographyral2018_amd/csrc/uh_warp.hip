@@ -12,15 +12,18 @@
 //     >4-byte-per-lane access at 4 lanes/clk, so 4 gathers + 1 store per pixel kept TA/TCP/TD busy ~100 %
 //     of the time (TCP_GATE_EN / TD_TD_BUSY = kernel duration; SQ_WAIT_INST_ANY = 69 % of wave cycles,
 //     i.e. waves waiting to ISSUE the next VMEM instruction) while HBM idled.
-//   * Now every wave owns a TW x (WY*STEPS) output tile (default 16 x 16).  It computes the sample
-//     coordinates of its 4 pixels/lane, reduces the bounding rectangle of all taps with DPP min/max (exact:
-//     no convexity assumption, no safety margin), pulls that source rectangle into a wave-private slice of
-//     LDS with wide (16 B/lane) row-contiguous loads -- each source byte crosses the TA once instead of up
-//     to 4 times -- and takes the 2x2 neighbourhoods from LDS (ds_read2_b32 + ds_read_b32 per tap).  No
-//     block barrier is involved: the producer and the consumers of a slice are lanes of the same wave.
+//   * Now every wave owns a TW x (WY*STEPS) output tile (default 16 x 16: a square footprint keeps the taps of
+//     a rotated tile on few source rows).  FORWARD: it computes the sample coordinates of its 4 pixels/lane,
+//     reduces the bounding rectangle of all taps with DPP min/max (exact: no convexity assumption, no safety
+//     margin), pulls that source rectangle into a wave-private 4 KiB slice of LDS with wide (16 B/lane)
+//     row-contiguous loads -- each source byte crosses the TA once instead of up to 4 times -- and takes the
+//     2x2 neighbourhoods from LDS (ds_read2_b32 + ds_read_b32 per tap).  No block barrier is involved: the
+//     producer and the consumers of a slice are lanes of the same wave.
 //   * A wave whose rectangle does not fit its LDS slice (far field of a strong perspective, where the
 //     footprint of 256 output pixels can be the whole frame) falls back to the direct gather; the choice is
 //     wave-uniform and both paths give bit-identical results.
+//   * BACKWARD: direct gather with all 16 tap loads of a lane in flight (UH_WARP_STAGE_BWD 0).  Staging was
+//     measured 15-30 % slower there in every variant tried.
 //   * blockIdx -> (image, tile) keeps the tiles of one image on one XCD (xcd_remap) so that the overlap of
 //     neighbouring rectangles is served by that XCD's L2.
 #include "uh_device.h"
@@ -41,7 +44,7 @@ namespace uh {
 #define UH_WARP_STAGE_FWD 1       // forward: stage through LDS when the rectangle fits (else gather)
 #endif
 #ifndef UH_WARP_STAGE_BWD
-#define UH_WARP_STAGE_BWD 0       // backward: direct gather only (measured equal or better: fewer VGPRs, no LDS)
+#define UH_WARP_STAGE_BWD 0       // backward: direct gather only (staging measured slower: profiles/r01g_*)
 #endif
 constexpr int TW = UH_WARP_TW;          // wave tile width (pixels)
 constexpr int WY = 64 / TW;             // rows a wave covers per step
