@@ -233,10 +233,11 @@ def main():
         'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: photometric-L1 train step, batch %d/GPU, %dx%d I/I\', %dx%d patch, '
-                               'RHO=%d, full-frame warp%s' % (B, args.img_h, args.img_w, args.patch_size,
-                                                              args.patch_size, args.rho,
-                                                              ' (fused patch kernel)' if args.fused_patch else ''),
+        'config': {'workload': '%s train step, batch %d/GPU, %dx%d I/I\', %dx%d patch, RHO=%d, full-frame warp%s' % (
+                       'configs[1]: photometric-L1' if args.loss_type == 'l1_loss' else
+                       ('configs[4]: supervised 4-pt (reference flag h_loss)' if args.loss_type == 'h_loss' else args.loss_type),
+                       B, args.img_h, args.img_w, args.patch_size, args.patch_size, args.rho,
+                       ' (fused patch kernel)' if args.fused_patch else ''),
                    'global_batch': global_batch, 'loss_type': args.loss_type, 'parallelism': 'dp%d' % world,
                    'final_loss': round(loss_val, 6)},
         'roofline': roofline,
