@@ -182,6 +182,7 @@ def main():
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     loss_val = float(model.loss.detach())
+    h_loss_val = float(model.h_loss.detach())              # mean corner error (RMSE px) of the last batch: the net is 35 steps old
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -239,7 +240,7 @@ def main():
                        B, args.img_h, args.img_w, args.patch_size, args.patch_size, args.rho,
                        ' (fused patch kernel)' if args.fused_patch else ''),
                    'global_batch': global_batch, 'loss_type': args.loss_type, 'parallelism': 'dp%d' % world,
-                   'final_loss': round(loss_val, 6)},
+                   'final_loss': round(loss_val, 6), 'mean_corner_error_px_after_%d_steps' % (args.steps + args.warmup): round(h_loss_val, 3)},
         'roofline': roofline,
     }
     if world == 1 and args.north_star:
