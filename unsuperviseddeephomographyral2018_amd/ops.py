@@ -130,7 +130,6 @@ class _ProjectiveWarp(torch.autograd.Function):
                                        _stream()), 'uh_warp_forward')
         ctx.save_for_backward(U, theta)
         ctx.dims = (B, H, W, Cc, out_h, out_w)
-        ctx.theta_shape = None
         if want_condition:
             ctx.mark_non_differentiable(cond)
             return out, cond
@@ -155,9 +154,7 @@ def transformer(U, theta, out_size, name='SpatialTransformer', with_condition=Tr
     """Spatial Transformer Layer -- same signature and return as the reference's
     transformer(U, theta, out_size) -> (output, condition)  (tf_spatial_transformer.py:18,249-251).
     theta may be [B,3,3], [B,9] ... anything reshapable to (-1,3,3) (:190)."""
-    th_shape = theta.shape
     res = _ProjectiveWarp.apply(U, theta.reshape(-1, 9), int(out_size[0]), int(out_size[1]), with_condition)
-    del th_shape
     if with_condition:
         return res[0], res[1][0]
     return res, None
