@@ -107,6 +107,16 @@ UH_API int uh_warp_backward(const float* U, const float* theta, const float* dOu
                      float* dTheta, float* dU, void* workspace, size_t workspace_bytes,
                      int B, int H, int W, int C, int oh, int ow, uh_stream_t stream);
 
+/* The same gradient when dOut is the gradient of the gray patch gather (homography_model.py:263-269): dPred [B,PP] and
+ * patch_idx [B,PP] stand for the frame gradient dPred[e]/C on the pixels patch_idx names, 0 elsewhere (out_size = H x W).
+ * Equals uh_gray_patch_backward -> uh_warp_backward for ANY index set, without materialising that frame: tiles that
+ * miss the patch rectangle are skipped, entries that are not at their rectangle position are added one by one.  On the
+ * dataloader's rectangles dTheta is bit-identical to the dense chain.                                               */
+UH_API size_t uh_warp_patch_backward_workspace_bytes(int B, int H, int W, int C);
+UH_API int uh_warp_patch_backward(const float* U, const float* theta, const float* dPred, const int* patch_idx,
+                           float* dTheta, void* workspace, size_t workspace_bytes,
+                           int B, int H, int W, int C, int PP, uh_stream_t stream);
+
 /* ---- gray + patch gather ------------------------------------------------------------------------
  * warped [B,H,W,C], patch_idx [B,PP] int32 (flat y*W+x within one image) -> pred [B,PP]
  * pred[k,i] = mean_c warped[k, patch_idx[k,i], c]                                                  */

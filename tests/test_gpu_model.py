@@ -209,6 +209,66 @@ def test_graph_tail_equals_unfused_chain(pkg, dev, fused):
     assert st['captures'] >= 1 and st['launches'] >= 3 and st['captures'] <= st['launches'] - 2, st
 
 
+def test_tail_plan_reentry_constants_and_address_churn(pkg, dev):
+    """Three hazards of the cached tail plan (VERDICT r1 / ADVICE r1):
+    (1) two forwards through the SAME plan before the first backward (second tower, gradient accumulation) must not
+        corrupt the first one's loss / pred / H / gradient -- outputs are copies, not views of plan buffers;
+    (2) the captured graph bakes M / Minv in as kernel arguments: re-running a plan with different M_host contents must
+        re-capture, not replay stale constants;
+    (3) a caller that hands in freshly allocated tensors every step must not pay a capture per step."""
+    hm, synthetic, _ = pkg
+    from unsuperviseddeephomographyral2018_amd import ops
+    batch = synthetic.make_batch(B, H, W, P, RHO, seed=21, device=dev)
+    ops.TailPlan._cache.clear()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    args = (batch['I_aug'], batch['I2_aug'], batch['patch_indices'], P)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    h1 = (torch.randn(B, 8, generator=g) * 3).to(dev); h2 = (torch.randn(B, 8, generator=g) * 3).to(dev)
+    with torch.cuda.stream(side):
+        # reference: each h4p alone
+        ref = []
+        for h in (h1, h2):
+            x = h.clone().requires_grad_(True)
+            l, pr, Hm, plan = ops.photometric_tail(batch['pts1'], x, *args, graph=True)
+            l.backward()
+            ref.append((float(l), pr.clone(), Hm.clone(), x.grad.clone()))
+        # (1) both forwards first, then both backwards
+        a = h1.clone().requires_grad_(True); b = h2.clone().requires_grad_(True)
+        la, pa, Ha, plan_a = ops.photometric_tail(batch['pts1'], a, *args, graph=True)
+        lb, pb, Hb, plan_b = ops.photometric_tail(batch['pts1'], b, *args, graph=True)
+        assert plan_a is plan_b
+        la.backward(); lb.backward()
+        side.synchronize()
+        assert float(la) == ref[0][0] and float(lb) == ref[1][0]
+        assert torch.equal(pa, ref[0][1]) and torch.equal(Ha, ref[0][2]) and torch.equal(a.grad, ref[0][3])
+        assert torch.equal(pb, ref[1][1]) and torch.equal(Hb, ref[1][2]) and torch.equal(b.grad, ref[1][3])
+        # (2) same plan, same pointers, different M / Minv (those of a 2x wider frame): theta changes, so pred must
+        M2, Minv2 = ops.m_and_minv(2 * W, H)
+        keep = (plan.M, plan.Minv, plan._Mh, plan._Mih)
+        plan._Mh = np.ascontiguousarray(M2.reshape(9), np.float32)
+        plan._Mih = np.ascontiguousarray(Minv2.reshape(9).astype(np.float32))
+        x = h1.clone().requires_grad_(True)
+        l2, p2, _, _ = ops.photometric_tail(batch['pts1'], x, *args, graph=True)
+        side.synchronize()
+        plan.M, plan.Minv, plan._Mh, plan._Mih = keep
+        assert not torch.equal(p2, ref[0][1])
+        x = h1.clone().requires_grad_(True)
+        l3, p3, _, _ = ops.photometric_tail(batch['pts1'], x, *args, graph=True)
+        side.synchronize()
+        assert torch.equal(p3, ref[0][1]) and float(l3) == ref[0][0]
+        # (3) fresh addresses every call: the capture count stops growing after the thrash threshold
+        c0 = plan.stats()['captures']
+        held = []
+        for i in range(24):
+            Ui = batch['I_aug'].clone(); held.append(Ui)             # kept alive => a new address every time
+            x = h1.clone().requires_grad_(True)
+            li, pi, _, _ = ops.photometric_tail(batch['pts1'], x, Ui, batch['I2_aug'], batch['patch_indices'], P, graph=True)
+            assert torch.equal(pi, ref[0][1])
+        side.synchronize()
+        assert plan.stats()['captures'] - c0 <= 9, plan.stats()
+
+
 def test_conv_bias_relu_epilogue_equals_torch(pkg, dev):
     """ops.conv_bias_relu (MIOpen conv + HIP bias/ReLU epilogue) vs F.relu(F.conv2d(x, w, b)): same forward bits,
     gradients within f32 reduction-order noise; and the whole regressor with / without the fused epilogue."""

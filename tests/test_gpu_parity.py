@@ -214,6 +214,111 @@ def test_warp_forward_lean_equals_literal_at_full_size(ops, dev, cfg):
     assert bool(same.all()), int((~same).sum())
 
 
+# ---------------------------------------------------------------------------------------------- config 4
+def _config4_inputs(n, seed=4):
+    """BASELINE.json configs[3]: 480x640 frames, 128x128 patch, rho = 64 (law of utils/gen_synthetic_data.py:42-53),
+    theta = DLT(gt + N(0, 2 px)) in f64 on the host, image 1 replaced by a far-field theta (t changes sign in frame)."""
+    H, W, P, rho = 480, 640, 128, 64
+    rs = np.random.RandomState(seed)
+    x0 = rs.randint(rho, W - rho - P + 1, n); y0 = rs.randint(rho, H - rho - P + 1, n)
+    pts1 = np.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).astype(np.float32)
+    h4p = (rs.randint(-rho, rho + 1, (n, 8)) + 2.0 * rs.randn(n, 8)).astype(np.float32)
+    theta = O.theta_from_H(O.solve_dlt_lapack64(pts1, h4p), W, H, np.float64).reshape(n, 3, 3).astype(np.float32)
+    theta[1] = np.array([[1, 0.05, 0], [-0.05, 1, 0], [0.8, 0.5, 0.3]], np.float32)
+    U = O.smooth_images(rs, n, H, W) if hasattr(O, 'smooth_images') else rs.randn(n, H, W, 3)
+    U = (np.asarray(U, np.float32) + 0.25 * rs.randn(n, H, W, 3)).astype(np.float32)
+    u = np.arange(P)
+    idx = ((u[None, :, None] + y0[:, None, None]) * W + (u[None, None, :] + x0[:, None, None])).reshape(n, P * P)
+    return H, W, P, U, theta, idx
+
+
+def test_config4_forward_vs_oracle(ops, dev):
+    """480x640, rho=64: EVERY pixel of three full frames against the f32 op-order oracle (bit level), the literal kernel
+    against the same oracle, and in-frame pixels against f64."""
+    H, W, P, U, theta, _ = _config4_inputs(3)
+    ref, c = O.transformer(U, theta, (H, W), np.float32)
+    out, cond = ops.transformer(T(U, dev), T(theta, dev), (H, W))
+    o = out.cpu().numpy()
+    m = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(o), m)
+    assert np.abs(o[m] - ref[m]).max() <= 1e-6 * max(1.0, np.abs(ref[m]).max())
+    assert (o[m] == ref[m]).mean() > 0.9999
+    assert float(cond) == float(c)
+    lit = ops.transformer_literal(T(U, dev), T(theta, dev), (H, W)).cpu().numpy()
+    assert np.abs(lit[m] - ref[m]).max() <= 1e-6 * max(1.0, np.abs(ref[m]).max())
+    assert (lit[m] == ref[m]).mean() > 0.9999
+    same = (o == lit) | (np.isnan(o) & np.isnan(lit))
+    assert same.all()
+    # f64 ground truth where the perspective divide is benign
+    w64, _ = O.transformer(U[[0, 2]], theta[[0, 2]].astype(np.float64), (H, W), np.float64)
+    xs, ys, t, xn, yn, _ = O.sample_coords(theta[[0, 2]].astype(np.float64), H, W, np.float64)
+    x = (xn + 1) * W / 2; y = (yn + 1) * H / 2
+    benign = ((x >= 0) & (x < W - 1) & (y >= 0) & (y < H - 1) & (np.abs(t) > 0.5)).reshape(2, H, W)
+    assert np.abs(o[[0, 2]] - w64)[benign].max() < 2e-4        # coordinates reach 640 px: eps32*640*few ops
+
+
+def test_literal_kernel_vs_oracle_small(ops, dev, golden):
+    """The literal transcription (validation kernel) against the oracle directly, so that lean == literal at
+    full size carries weight."""
+    g = golden('chain_small.npz')
+    lit = ops.transformer_literal(T(g['I'], dev), T(g['theta32'], dev), (60, 80)).cpu().numpy()
+    assert np.abs(lit - g['warped32']).max() <= 1e-6
+    assert (lit == g['warped32']).mean() > 0.999
+
+
+@pytest.mark.parametrize('kind', ['dense', 'patch'])
+def test_config4_backward_vs_oracle(ops, dev, kind):
+    """dTheta at 480x640, rho=64 against the f64 closed form at the f32 sample positions: dense random dOut and the
+    sparse dOut the photometric loss produces (non-zero only inside the 128x128 patch rectangle).
+    Tolerance.  rho = 64 on a 128 px patch is a violent law: in most draws t changes sign INSIDE the frame, single
+    samples contribute ~1/t and ~1/t^2 (|t| down to 1e-6) and the sum cancels by 3-5 orders of magnitude, so an f32
+    evaluation -- ours, or NumPy's (1e-3 off the f64 value on these inputs) -- is only defined up to eps32 * sum|terms|.
+    The bound is therefore  |got - ref| <= 1e-4 * max|ref|  +  16 * eps32 * sum|terms|  (elementwise); image 2 is a
+    mid-training theta (no sign change) where the second term is negligible and the first one decides."""
+    H, W, P, U, theta, idx = _config4_inputs(3, seed=5)
+    rs = np.random.RandomState(11)
+    # image 2: benign theta = DLT(pts, small h4p)
+    pts1 = np.array([[200, 150, 328, 150, 328, 278, 200, 278]], np.float32)
+    theta[2] = O.theta_from_H(O.solve_dlt_lapack64(pts1, (12 * rs.randn(1, 8)).astype(np.float32)), W, H,
+                              np.float64).reshape(3, 3).astype(np.float32)
+    if kind == 'dense':
+        g = rs.randn(3, H, W, 3).astype(np.float32)
+    else:
+        g = np.zeros((3, H * W, 3), np.float32)
+        for k in range(3):
+            g[k, idx[k]] = (rs.randn(P * P, 1) / 3.0).astype(np.float32)       # d gray / d channel = 1/3 each
+        g = g.reshape(3, H, W, 3)
+    tt = T(theta, dev).requires_grad_(True)
+    ops.transformer(T(U, dev), tt, (H, W))[0].backward(T(g, dev))
+    ref, cond = O.transformer_backward(U, theta, g, (H, W), np.float64, coord_dtype=np.float32, want_abs=True)
+    got = tt.grad.cpu().numpy().reshape(-1, 3, 3).astype(np.float64)
+    eps32 = float(np.finfo(np.float32).eps)
+    for k in range(3):
+        bound = 1e-4 * np.abs(ref[k]).max() + 16 * eps32 * cond[k]
+        assert (np.abs(got[k] - ref[k]) <= bound).all(), (kind, k, np.abs(got[k] - ref[k]).max(), bound.min())
+    assert relerr(got[2], ref[2]) < 2e-4                       # the well-conditioned image, plain relative error
+
+
+def test_warp_backward_dU_large_and_far_field(ops, dev):
+    """dU (the library's only float-atomic path) at 240x320 on the benchmark law, a far-field theta and a theta that
+    collapses corner pairs on the border."""
+    rs = np.random.RandomState(19)
+    B, H, W, C = 3, 240, 320, 3
+    d = O.synthetic_batch(3, 1, H=H, W=W, P=128, rho=45)
+    U = rs.randn(B, H, W, C).astype(np.float32)
+    th0 = O.theta_from_H(O.solve_dlt_lapack64(d['pts1'], d['pred_h4p']), W, H, np.float64).reshape(3, 3)
+    theta = np.stack([th0, [[1, 0.05, 0], [-0.05, 1, 0], [0.8, 0.5, 0.3]], [[1, 0, 0.7], [0, 1, -0.6], [0, 0, 1]]]).astype(np.float32)
+    g = rs.randn(B, H, W, C).astype(np.float32)
+    Ut = T(U, dev).requires_grad_(True); tt = T(theta, dev).requires_grad_(True)
+    ops.transformer(Ut, tt, (H, W))[0].backward(T(g, dev))
+    dth, dU = O.transformer_backward(U, theta, g, (H, W), np.float64, want_dU=True, coord_dtype=np.float32)
+    got = Ut.grad.cpu().numpy()
+    for k in range(B):
+        scale = max(np.abs(dU[k]).max(), 1.0)
+        assert np.abs(got[k] - dU[k]).max() < 1e-4 * scale, (k, np.abs(got[k] - dU[k]).max(), scale)
+        assert relerr(tt.grad.cpu().numpy().reshape(-1, 3, 3)[k], dth[k]) < 2e-4, k
+
+
 def test_warp_forward_large_image_offsets(ops, dev):
     """An image of more than 2^24 bytes takes the integer-offset path (offsets no longer exact in f32)."""
     rs = np.random.RandomState(5)
@@ -363,6 +468,76 @@ def test_gray_patch_backward_index_sets(ops, dev, case):
     for k in range(B):
         np.add.at(ref[k], idx[k], (dP[k].astype(np.float64) / C)[:, None])
     assert np.abs(dW.cpu().numpy().reshape(B, H * W, C) - ref).max() <= 1e-6
+
+
+@pytest.mark.parametrize('case', ['rect', 'rect_wrapping_row', 'rect_with_swaps_and_dups', 'random', 'non_square'])
+def test_warp_patch_backward_equals_dense_chain(ops, dev, case):
+    """uh_warp_patch_backward (sparse: dPred + indices, tiles outside the patch rectangle skipped, stray entries added one
+    by one) against the dense chain it replaces, uh_gray_patch_backward -> uh_warp_backward, on the same index sets as
+    above: bit-identical on true rectangles, <= 1e-5 relative where stray entries take the f64 fix-up path."""
+    rs = np.random.RandomState(hash(case) % 1000 + 7)
+    B, H, W, C, P = 3, 60, 92, 3, 24
+    PP = P * P
+    u = np.arange(P)
+    x0 = np.array([3, 40, 66]); y0 = np.array([2, 19, 33])
+    if case == 'rect_wrapping_row':
+        x0 = np.array([80, 75, 70])
+    idx = ((u[None, :, None] + y0[:, None, None]) * W + (u[None, None, :] + x0[:, None, None])).reshape(B, PP)
+    if case == 'rect_with_swaps_and_dups':
+        idx[0, [3, 17]] = idx[0, [17, 3]]; idx[1, 5] = idx[1, 6]; idx[2, 0] = idx[2, 35]
+    elif case == 'random':
+        idx = rs.randint(0, H * W, (B, PP))
+    elif case == 'non_square':
+        PP = 500; idx = idx[:, :PP]
+    idx = np.clip(idx, 0, H * W - 1).astype(np.int32)
+    U = T(rs.randn(B, H, W, C).astype(np.float32), dev)
+    theta = (np.tile(np.eye(3), (B, 1, 1)) + 0.08 * rs.randn(B, 3, 3)).astype(np.float32)
+    theta[2] = np.array([[1, 0.05, 0], [-0.05, 1, 0], [0.8, 0.5, 0.3]], np.float32)        # far field inside the frame
+    dP = T(rs.randn(B, PP).astype(np.float32), dev)
+    tidx = T(idx, dev)
+    from unsuperviseddeephomographyral2018_amd import _lib
+    import ctypes as C_
+    lib = _lib.load()
+    p = lambda t: C_.c_void_p(t.data_ptr())
+    st = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tth = T(theta.reshape(B, 9), dev)
+    # dense chain
+    dW = torch.empty(B, H, W, C, device=dev)
+    _lib.check(lib.uh_gray_patch_backward(p(dP), p(tidx), p(dW), B, H, W, C, PP, st), 'gray_bwd')
+    nb = lib.uh_warp_backward_workspace_bytes(B, H, W, C, H, W); ws = torch.empty(nb // 4, device=dev)
+    dT_dense = torch.empty(B, 9, device=dev)
+    _lib.check(lib.uh_warp_backward(p(U), p(tth), p(dW), p(dT_dense), None, p(ws), nb, B, H, W, C, H, W, st), 'warp_bwd')
+    # sparse
+    nb2 = lib.uh_warp_patch_backward_workspace_bytes(B, H, W, C); ws2 = torch.empty(nb2 // 4, device=dev)
+    dT = torch.full((B, 9), 7.0, device=dev)
+    _lib.check(lib.uh_warp_patch_backward(p(U), p(tth), p(dP), p(tidx), p(dT), p(ws2), nb2, B, H, W, C, PP, st), 'patch_bwd')
+    a, b = dT.cpu().numpy(), dT_dense.cpu().numpy()
+    if case in ('rect', 'rect_wrapping_row'):
+        assert np.array_equal(a, b)
+    else:
+        for k in range(B):
+            assert relerr(a[k], b[k]) < 1e-5, (case, k, a[k], b[k])
+    # error behaviour through the ABI
+    assert lib.uh_warp_patch_backward(p(U), p(tth), p(dP), p(tidx), p(dT), p(ws2), 16, B, H, W, C, PP, st) == -4
+    assert lib.uh_warp_patch_backward(p(U), p(tth), None, p(tidx), p(dT), p(ws2), nb2, B, H, W, C, PP, st) == -1
+
+
+def test_warp_gather_node_matches_two_node_chain(ops, dev):
+    """ops.warp_gather (reference transform() as one autograd node with the sparse backward) against
+    ops.transformer -> ops.gray_patch_gather at the BASELINE size: same warped frame, same pred, same d/dtheta bits."""
+    B, H, W, P = 8, 240, 320, 128
+    d = O.synthetic_batch(6, B, H=H, W=W, P=P, rho=45)
+    U, idx = T(d['I'], dev), T(d['patch_indices'], dev)
+    _, theta = ops.solve_dlt(T(d['pts1'], dev), T(d['pred_h4p'], dev), img_w=W, img_h=H)
+    g = torch.randn(B, P, P, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    t1 = theta.detach().clone().requires_grad_(True); t2 = theta.detach().clone().requires_grad_(True)
+    w1, _ = ops.transformer(U, t1, (H, W), with_condition=False)
+    p1 = ops.gray_patch_gather(w1, idx, P)
+    p1.backward(g)
+    w2, p2 = ops.warp_gather(U, t2, idx, P)
+    p2.backward(g)
+    assert torch.equal(w1, w2) and torch.equal(p1, p2)
+    assert torch.equal(t1.grad, t2.grad)
 
 
 # ---------------------------------------------------------------------------------------------- chain

@@ -29,6 +29,8 @@ SIGNATURES = {
     'uh_warp_forward_literal': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'uh_warp_backward_workspace_bytes': (_z, [_i, _i, _i, _i, _i, _i]),
     'uh_warp_backward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),
+    'uh_warp_patch_backward_workspace_bytes': (_z, [_i, _i, _i, _i]),
+    'uh_warp_patch_backward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
     'uh_gray_patch_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'uh_gray_patch_backward': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'uh_l1_loss_workspace_bytes': (_z, [_z]),

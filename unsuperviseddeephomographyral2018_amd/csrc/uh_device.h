@@ -154,6 +154,7 @@ struct Coord {
 struct TapOff { unsigned oa, ob, oc, od; };
 struct Tap : TapOff {
     float ax1, ax0, ay1, ay0;
+    float hx, hy;                   // x1f - x0f, y1f - y0f: 1, or 0 where the clip collapsed the pair
     float xs, ys, t, rt;
 };
 
@@ -167,15 +168,22 @@ __device__ __forceinline__ void clip_pair(float v, float hi, float& c0, float& c
     c1 = __builtin_amdgcn_fmed3f(fl + 1.0f, 0.0f, hi);                                      // (:107,109)
 }
 
-// A0/A3/A6 = theta[0]*gx, theta[3]*gx, theta[6]*gx (hoisted: gx is fixed per lane); gy varies per row.
-__device__ __forceinline__ Coord make_coord(const Theta& th, float A0, float A3, float A6, float gy, const SrcGeom& g) {
-    Coord s;
+// ---- the sampling law in two halves --------------------------------------------------------------------
+// project(): everything up to the pixel coordinates (x, y) -- shared by every path of the bandwidth kernels.
+// clip_coord(): floor/clip/weights for samples that may touch the border (what make_coord() does after x, y).
+// A wave whose samples are ALL strictly interior (0 <= floor(x), floor(x)+1 <= W-1, same for y: decided once per
+// wave from an exact min/max reduction of the floors) skips clip_coord(): there x0f = floor(x), x1f = x0f+1, and
+//   ax0 = x - x0f          exact (fractional part of a non-negative float)
+//   ax1 = (x0f+1) - x      == 1 - ax0 bit for bit: both round the same real number 1 - frac(x)
+// and the four taps sit at oa, oa+pixB, oa+pitch, oa+pitch+pixB: ONE offset instead of four.
+struct Proj { float xs, ys, t, rt, x, y; };
+__device__ __forceinline__ Proj project(const Theta& th, float A0, float A3, float A6, float gy, const SrcGeom& g) {
+    Proj s;
     s.xs = (A0 + th.a[1] * gy) + th.a[2];                                                   // (:213)
     s.ys = (A3 + th.a[4] * gy) + th.a[5];
     float t = (A6 + th.a[7] * gy) + th.a[8];
     t = (fabsf(t) >= 1e-7f) ? t : t + 1e-6f;         // == t + 1e-6*(1 - [|t| >= 1e-7])        (:230-234)
     s.t = t;
-    // xs/t and ys/t, IEEE-exact, one shared reciprocal (see the header comment)
     const float y0 = __builtin_amdgcn_rcpf(t);
     const float e0 = __builtin_fmaf(-t, y0, 1.0f);
     const float y1 = __builtin_fmaf(e0, y0, y0);
@@ -185,13 +193,23 @@ __device__ __forceinline__ Coord make_coord(const Theta& th, float A0, float A3,
     r = __builtin_fmaf(-t, q, s.xs); const float xn = __builtin_fmaf(r, y1, q);             // (:239)
     q = s.ys * y1; r = __builtin_fmaf(-t, q, s.ys); q = __builtin_fmaf(r, y1, q);
     r = __builtin_fmaf(-t, q, s.ys); const float yn = __builtin_fmaf(r, y1, q);             // (:240)
-    const float x = ((xn + 1.0f) * g.Wf) * 0.5f;     // /2 == *0.5 exactly                      (:97)
-    const float y = ((yn + 1.0f) * g.Hf) * 0.5f;                                            // (:98)
-    clip_pair(x, g.Wm1, s.x0f, s.x1f);
-    clip_pair(y, g.Hm1, s.y0f, s.y1f);
-    s.ax1 = s.x1f - x;  s.ax0 = x - s.x0f;                                                  // (:130-137)
-    s.ay1 = s.y1f - y;  s.ay0 = y - s.y0f;
+    s.x = ((xn + 1.0f) * g.Wf) * 0.5f;               // /2 == *0.5 exactly                      (:97)
+    s.y = ((yn + 1.0f) * g.Hf) * 0.5f;                                                      // (:98)
     return s;
+}
+__device__ __forceinline__ Coord clip_coord(const Proj& p, const SrcGeom& g) {
+    Coord s;
+    s.xs = p.xs; s.ys = p.ys; s.t = p.t; s.rt = p.rt;
+    clip_pair(p.x, g.Wm1, s.x0f, s.x1f);
+    clip_pair(p.y, g.Hm1, s.y0f, s.y1f);
+    s.ax1 = s.x1f - p.x;  s.ax0 = p.x - s.x0f;                                              // (:130-137)
+    s.ay1 = s.y1f - p.y;  s.ay0 = p.y - s.y0f;
+    return s;
+}
+
+// A0/A3/A6 = theta[0]*gx, theta[3]*gx, theta[6]*gx (hoisted: gx is fixed per lane); gy varies per row.
+__device__ __forceinline__ Coord make_coord(const Theta& th, float A0, float A3, float A6, float gy, const SrcGeom& g) {
+    return clip_coord(project(th, A0, A3, A6, gy, g), g);
 }
 
 // tap offsets inside the image in global memory
@@ -230,6 +248,7 @@ __device__ __forceinline__ Tap make_tap(const Theta& th, float A0, float A3, flo
     Tap s;
     static_cast<TapOff&>(s) = global_offsets<SMALL>(c, g);
     s.ax1 = c.ax1; s.ax0 = c.ax0; s.ay1 = c.ay1; s.ay0 = c.ay0;
+    s.hx = c.x1f - c.x0f; s.hy = c.y1f - c.y0f;
     s.xs = c.xs; s.ys = c.ys; s.t = c.t; s.rt = c.rt;
     return s;
 }

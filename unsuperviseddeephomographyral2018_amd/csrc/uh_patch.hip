@@ -92,10 +92,14 @@ __global__ __launch_bounds__(256) void warp_patch_l1_kernel(
             if (WANT_GRAD) {
                 const float sgn = d > 0.f ? m : (d < 0.f ? -m : 0.f);
                 float ex = 0.f, ey = 0.f;
+                // lerp form of ay1 (Ic-Ia) + ay0 (Id-Ib): exact 0 where the clip collapsed a pair (see uh_warp.hip)
+                const float hx = s[k].hx, hy = s[k].hy;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    ex += fmaf(s[k].ay1, Ic[k].v[c] - Ia[k].v[c], s[k].ay0 * (Id[k].v[c] - Ib[k].v[c]));
-                    ey += fmaf(s[k].ax1, Ib[k].v[c] - Ia[k].v[c], s[k].ax0 * (Id[k].v[c] - Ic[k].v[c]));
+                    const float dca = Ic[k].v[c] - Ia[k].v[c], ddb = Id[k].v[c] - Ib[k].v[c];
+                    const float dba = Ib[k].v[c] - Ia[k].v[c], ddc = Id[k].v[c] - Ic[k].v[c];
+                    ex += fmaf(s[k].ay1, dca - ddb, hy * ddb);
+                    ey += fmaf(s[k].ax1, dba - ddc, hx * ddc);
                 }
                 const float gg = sgn / (float)C;
                 const float rt = s[k].rt;

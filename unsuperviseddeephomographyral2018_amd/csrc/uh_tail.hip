@@ -18,10 +18,14 @@ struct uh_tail_plan {
     unsigned flags;
     // workspace layout (byte offsets, 256-byte aligned)
     size_t off_theta, off_dtheta, off_warped, off_dwarped, off_dpred, off_ws_warp, off_ws_l1, off_ws_patch, off_one, total;
-    struct Entry { const void* key[12]; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; };
+    // A captured graph bakes in every kernel ARGUMENT: the pointers and the M / Minv constants (passed by value to the
+    // DLT kernels).  The key therefore holds both; a caller that re-runs a plan with different M_host contents gets a
+    // fresh capture, never stale constants.
+    struct Entry { const void* key[12]; float mk[18]; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; };
     std::vector<Entry> cache;
     unsigned long long clock = 0;
     long long launches = 0, captures = 0;
+    int misses_in_a_row = 0;          // capture thrash detector (see uh_tail_run)
     std::mutex mu;
 };
 
@@ -121,11 +125,19 @@ extern "C" int uh_tail_run(uh_tail_plan* p, const float* pts1, const float* h4p,
     float mk[18];
     std::memcpy(mk, M_host, 9 * sizeof(float)); std::memcpy(mk + 9, Minv_host, 9 * sizeof(float));
     for (auto& e : p->cache) {
-        if (std::memcmp(e.key, key, sizeof(key)) == 0) {
+        if (std::memcmp(e.key, key, sizeof(key)) == 0 && std::memcmp(e.mk, mk, sizeof(mk)) == 0) {
             e.stamp = ++p->clock;
             p->launches++;
+            p->misses_in_a_row = 0;
             return (int)hipGraphLaunch(e.exec, s);
         }
+    }
+    // A caller that hands in freshly allocated batches every step (new addresses each time) would pay a capture +
+    // instantiate on the hot path per step -- slower than the ten eager launches it replaces.  After a full cache
+    // worth of consecutive misses stop capturing and enqueue eagerly until an address set repeats.
+    if (++p->misses_in_a_row > 8) {
+        p->launches++;
+        return enqueue_chain(p, pts1, h4p, U, I2, patch_idx, M_host, Minv_host, H, pred, loss, dh4p, ws, s);
     }
     // capture the chain on the caller's stream (thread-local mode: other threads' HIP calls are unaffected)
     hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
@@ -145,7 +157,7 @@ extern "C" int uh_tail_run(uh_tail_plan* p, const float* pts1, const float* h4p,
         p->cache.erase(p->cache.begin() + v);
     }
     uh_tail_plan::Entry en;
-    std::memcpy(en.key, key, sizeof(key)); en.graph = graph; en.exec = exec; en.stamp = ++p->clock;
+    std::memcpy(en.key, key, sizeof(key)); std::memcpy(en.mk, mk, sizeof(mk)); en.graph = graph; en.exec = exec; en.stamp = ++p->clock;
     p->cache.push_back(en);
     p->captures++; p->launches++;
     return (int)hipGraphLaunch(exec, s);

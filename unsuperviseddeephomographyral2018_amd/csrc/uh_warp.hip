@@ -5,25 +5,24 @@
 // intermediates (~600 B/pixel); here each output pixel is produced in registers: algorithmic traffic
 // is read U + write out (forward) and read dOut + read U (backward), 2*B*H*W*C*4 bytes each.
 //
-// Design (what the measurements forced -- DESIGN.md "Warp kernels"):
-//   * The first version gathered the 2x2 neighbourhood straight from global memory: 4 per-lane 12-byte
-//     loads per pixel.  HBM traffic was already minimal (FETCH/WRITE counters = unique footprint) but the
-//     kernel ran at 45-60 % of a same-bytes copy: the vector-memory pipe (TA -> TCP -> TD) processes a
-//     >4-byte-per-lane access at 4 lanes/clk, so 4 gathers + 1 store per pixel kept TA/TCP/TD busy ~100 %
-//     of the time (TCP_GATE_EN / TD_TD_BUSY = kernel duration; SQ_WAIT_INST_ANY = 69 % of wave cycles,
-//     i.e. waves waiting to ISSUE the next VMEM instruction) while HBM idled.
-//   * Now every wave owns a TW x (WY*STEPS) output tile (default 16 x 16: a square footprint keeps the taps of
-//     a rotated tile on few source rows).  FORWARD: it computes the sample coordinates of its 4 pixels/lane,
-//     reduces the bounding rectangle of all taps with DPP min/max (exact: no convexity assumption, no safety
-//     margin), pulls that source rectangle into a wave-private 4 KiB slice of LDS with wide (16 B/lane)
-//     row-contiguous loads -- each source byte crosses the TA once instead of up to 4 times -- and takes the
-//     2x2 neighbourhoods from LDS (ds_read2_b32 + ds_read_b32 per tap).  No block barrier is involved: the
-//     producer and the consumers of a slice are lanes of the same wave.
-//   * A wave whose rectangle does not fit its LDS slice (far field of a strong perspective, where the
-//     footprint of 256 output pixels can be the whole frame) falls back to the direct gather; the choice is
-//     wave-uniform and both paths give bit-identical results.
-//   * BACKWARD: direct gather with all 16 tap loads of a lane in flight (UH_WARP_STAGE_BWD 0).  Staging was
-//     measured 15-30 % slower there in every variant tried.
+// Design (what the measurements forced -- DESIGN.md 3.1):
+//   * HBM traffic has been minimal since the first version (FETCH/WRITE counters = unique footprint); what the
+//     kernels are short of is INSTRUCTION ISSUE: round 1 ended at ~140 VALU instructions per pixel-lane with the
+//     VALU ~60-75 % busy and a 12-byte gather costing 16.5 TA cycles per wave.  Round 2 therefore splits the
+//     sampling law (uh_device.h: project() / clip_coord()) and gives every wave one of three paths, chosen
+//     wave-uniformly from an EXACT min/max reduction of floor(x), floor(y) over the wave's pixels (DPP):
+//       A  interior + rectangle fits the wave's LDS slice: the source rectangle is pulled into LDS by LDS-DMA
+//          (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write), rows packed at pitch = 16*ceil(12*w/16);
+//          no clipping, ONE tap offset per pixel, the 2x2x3 neighbourhood is 6 ds_read2_b32 at constant offsets;
+//          the per-pixel weights are formed while the DMA is in flight;
+//       B  interior, rectangle too large (minifying regions): same cheap arithmetic, taps gathered from global
+//          memory with two offsets per pixel (the x+1 taps ride on the instruction's immediate offset);
+//       C  some tap is clipped (27-29 % of the tiles at the benchmark laws): the round-1 gather with clip_coord().
+//     All three produce identical bits (tests/test_gpu_parity.py compares them with the f32 oracle and with the
+//     literal kernel below at full size).
+//   * Every wave owns a TW x (WY*STEPS) output tile (default 16 x 16: a square footprint keeps the taps of
+//     a rotated tile on few source rows).  No block barrier is involved in the forward: the producer and the
+//     consumers of an LDS slice are lanes of the same wave.
 //   * blockIdx -> (image, tile) keeps the tiles of one image on one XCD (xcd_remap) so that the overlap of
 //     neighbouring rectangles is served by that XCD's L2.
 #include "uh_device.h"
@@ -38,13 +37,16 @@ namespace uh {
 #define UH_WARP_STEPS 4
 #endif
 #ifndef UH_WARP_LDS_PER_WAVE
-#define UH_WARP_LDS_PER_WAVE 4096
+#define UH_WARP_LDS_PER_WAVE 6144  // forward: LDS slice per wave (path A holds rectangles up to this size)
+#endif
+#ifndef UH_WARP_LDS_PER_WAVE_BWD
+#define UH_WARP_LDS_PER_WAVE_BWD 6144
 #endif
 #ifndef UH_WARP_STAGE_FWD
-#define UH_WARP_STAGE_FWD 1       // forward: stage through LDS when the rectangle fits (else gather)
+#define UH_WARP_STAGE_FWD 1       // 0: path A off (developer A/B switch)
 #endif
 #ifndef UH_WARP_STAGE_BWD
-#define UH_WARP_STAGE_BWD 0       // backward: direct gather only (staging measured slower: profiles/r01g_*)
+#define UH_WARP_STAGE_BWD 1
 #endif
 constexpr int TW = UH_WARP_TW;          // wave tile width (pixels)
 constexpr int WY = 64 / TW;             // rows a wave covers per step
@@ -61,11 +63,31 @@ constexpr int STEPS = UH_WARP_STEPS;    // pixels per lane (forward)
 constexpr int TH = WY * STEPS;          // wave tile height (forward)
 constexpr int STEPS_B = UH_WARP_STEPS_BWD;   // pixels per lane (backward)
 constexpr int TH_B = WY * STEPS_B;           // wave tile height (backward)
+#ifndef UH_WARP_BWD_BATCH
+#define UH_WARP_BWD_BATCH 2       // backward gather paths (B, C): pixels per lane whose taps are in flight together
+#endif
+constexpr int BT_B = UH_WARP_BWD_BATCH;
+#ifndef UH_WARP_FWD_BATCH
+#define UH_WARP_FWD_BATCH 2       // forward gather paths (B, C): the same
+#endif
+constexpr int BT_F = UH_WARP_FWD_BATCH;
+#ifndef UH_WARP_FWD_TPB
+#define UH_WARP_FWD_TPB 1         // forward: consecutive tiles one block walks
+#endif
+constexpr int TPB_F = UH_WARP_FWD_TPB;
+static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the steps");
+#ifndef UH_WARP_FWD_MINW
+#define UH_WARP_FWD_MINW 1        // __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow
+#endif
+#ifndef UH_WARP_BWD_MINW
+#define UH_WARP_BWD_MINW 1
+#endif
+static_assert(UH_WARP_STEPS_BWD % UH_WARP_BWD_BATCH == 0, "batch must divide the steps");
 constexpr int NWAVE = 4;                // waves per block, side by side in x: block tile = (4*TW) x TH
-constexpr int LDS_PER_WAVE = UH_WARP_LDS_PER_WAVE;
 constexpr bool STAGE_FWD = UH_WARP_STAGE_FWD != 0, STAGE_BWD = UH_WARP_STAGE_BWD != 0;
 static_assert(TW * WY == 64, "UH_WARP_TW must divide 64");
-static_assert(LDS_PER_WAVE % 1024 == 0 && LDS_PER_WAVE <= 16384, "LDS slice: multiple of 1 KiB, <= 16 KiB");
+static_assert(UH_WARP_LDS_PER_WAVE % 1024 == 0 && UH_WARP_LDS_PER_WAVE <= 16384, "LDS slice: multiple of 1 KiB, <= 16 KiB");
+static_assert(UH_WARP_LDS_PER_WAVE_BWD % 1024 == 0 && UH_WARP_LDS_PER_WAVE_BWD <= 16384, "LDS slice: multiple of 1 KiB, <= 16 KiB");
 
 struct TileGeom { int tiles_x, tiles_y, tiles; };
 static inline TileGeom tile_geom(int oh, int ow, int th = TH) {
@@ -83,90 +105,142 @@ __device__ __forceinline__ Theta load_theta(const float* __restrict__ theta, int
     return th;
 }
 
-// Rectangle of all taps of this wave (exact: min/max over the clipped corners of every pixel of the wave), the
-// LDS layout chosen for it, and whether it fits the wave's LDS slice.
-//   LDS layout: row r of the rectangle at r*pitch; pitch = cw*16 bytes with cw = 16, 32 or 64 chunks of 16 bytes
-//   (the smallest that covers the rectangle's row), so that lane -> (row, chunk) is a shift and a mask.
-struct Rect {
-    int bx0, by0;        // top-left source pixel of the rectangle
-    int cpr;             // 16-byte chunks that actually carry data in one row
-    int sh;              // log2(cw)
-    int iters;           // staging iterations, each moves 64 >> sh ... rows
-    float pitch, nbase;  // pitch in bytes; nbase = -(by0*pitch + bx0*pixB)
-    bool fits;
+// ---- wave-uniform path decision ------------------------------------------------------------------------
+// Exact extent of floor(x), floor(y) over every pixel of the wave.  The reduction runs on the f32 BIT PATTERNS as
+// signed integers: for non-negative floats that order is the numeric order; a negative float (or -NaN) anywhere
+// makes the minimum negative, a +NaN / huge value makes the maximum exceed any valid bound -- both fail the
+// interior test below, and nothing else is read from the result in that case.
+struct Extent {
+    bool interior;          // every tap of every pixel is an un-clipped source pixel
+    int bx0, by0;           // top-left source pixel of the tap rectangle (interior only)
+    int rw, rh;             // its width / height in pixels
 };
-template <int C, int N>
-__device__ __forceinline__ Rect wave_rect(const Coord (&c)[N]) {
-    // the clipped corners are exact non-negative integers held in f32: their bit patterns order like integers
-    int mnx = __float_as_int(c[0].x0f), mxx = __float_as_int(c[0].x1f);
-    int mny = __float_as_int(c[0].y0f), mxy = __float_as_int(c[0].y1f);
+template <int N>
+__device__ __forceinline__ Extent wave_extent(const float (&fx)[N], const float (&fy)[N], const SrcGeom& g) {
+    int mnx = __float_as_int(fx[0]), mxx = mnx, mny = __float_as_int(fy[0]), mxy = mny;
 #pragma unroll
     for (int k = 1; k < N; ++k) {
-        mnx = min(mnx, __float_as_int(c[k].x0f)); mxx = max(mxx, __float_as_int(c[k].x1f));
-        mny = min(mny, __float_as_int(c[k].y0f)); mxy = max(mxy, __float_as_int(c[k].y1f));
+        mnx = min(mnx, __float_as_int(fx[k])); mxx = max(mxx, __float_as_int(fx[k]));
+        mny = min(mny, __float_as_int(fy[k])); mxy = max(mxy, __float_as_int(fy[k]));
     }
-    const float fx0 = __int_as_float(wave_min_nonneg(mnx)), fx1 = __int_as_float(wave_max_nonneg(mxx));
-    const float fy0 = __int_as_float(wave_min_nonneg(mny)), fy1 = __int_as_float(wave_max_nonneg(mxy));
-    Rect r;
-    r.bx0 = (int)fx0; r.by0 = (int)fy0;
-    const int rw = (int)fx1 - r.bx0 + 1, rh = (int)fy1 - r.by0 + 1;
-    r.cpr = (rw * C * 4 + 15) >> 4;
-    r.sh = r.cpr <= 16 ? 4 : (r.cpr <= 32 ? 5 : 6);
-    const int rpi = 64 >> r.sh;                           // rows per staging iteration
-    r.iters = (rh + rpi - 1) / rpi;
-    const int pitch = 16 << r.sh;
-    r.fits = r.cpr <= 64 && r.iters * rpi * pitch <= LDS_PER_WAVE;
-    r.pitch = (float)pitch;
-    r.nbase = -((float)r.by0 * r.pitch + (float)(r.bx0 * C * 4));
-    return r;
+    mnx = wave_min_nonneg(mnx); mxx = wave_max_nonneg(mxx);      // (valid for any sign at lane 63, see uh_device.h)
+    mny = wave_min_nonneg(mny); mxy = wave_max_nonneg(mxy);
+    Extent e;
+    // floor(x) >= 0 and floor(x) + 1 <= W - 1   (bit patterns of non-negative floats compare like the floats)
+    e.interior = mnx >= 0 && mny >= 0 && mxx <= __float_as_int(g.Wm1 - 1.0f) && mxy <= __float_as_int(g.Hm1 - 1.0f)
+                 && g.Wm1 >= 1.0f && g.Hm1 >= 1.0f;
+    e.bx0 = (int)__int_as_float(mnx); e.by0 = (int)__int_as_float(mny);
+    e.rw = (int)__int_as_float(mxx) - e.bx0 + 2; e.rh = (int)__int_as_float(mxy) - e.by0 + 2;
+    return e;
 }
 
-// Stage the rectangle into this wave's LDS slice with 16-byte-per-lane loads: lane = (row r, chunk c) with
-// r = lane >> sh, c = lane & (cw-1); iteration i moves rows i*rpi + r.  The global address of chunk c of row r,
-// ((by0+r)*W + bx0)*C*4 + c*16, is only 4-byte aligned, which costs nothing on global loads (tools/ubench:
-// misaligned b128 == aligned b128).  Chunks c >= cpr (padding of the power-of-two pitch) and rows past the end
-// of the image get an out-of-range offset: the buffer unit returns zeros without touching memory; the LDS
-// write needs no mask because `fits` accounted for the padded footprint.  Per iteration: one VALU add (global
-// offset), one buffer_load_dwordx4, one ds_write_b128 (LDS step folded into the instruction offset).
-template <int C>
-__device__ __forceinline__ void stage_rect(__amdgpu_buffer_rsrc_t rin, unsigned char* lds, int lane, const Rect& r,
-                                           int rowBi) {
-    const int rr = lane >> r.sh, cc = lane & ((1 << r.sh) - 1);
-    const unsigned goff = cc < r.cpr ? (unsigned)(r.by0 + rr) * (unsigned)rowBi + (unsigned)(r.bx0 * C * 4 + cc * 16)
-                                     : 0x80000000u;
-    unsigned char* lp = lds + lane * 16;                   // == rr*pitch + cc*16
-    const unsigned gstep = (unsigned)(64 >> r.sh) * (unsigned)rowBi;
-    // the row step goes into the VGPR offset (not soffset): the buffer unit range-checks the VGPR offset, which is
-    // what turns rows past the end of the image into zeros instead of reads past the allocation
+// ---- path A staging: LDS-DMA of the tap rectangle ------------------------------------------------------------
+// The rectangle's rows are cut into 16-byte chunks, cpr = ceil(rw*C*4/16) per row, and chunk q = r*cpr + c goes to
+// LDS byte 16*q: one buffer_load_dwordx4 ... lds moves 64 consecutive chunks (1 KiB) straight into the slice (the
+// LDS address of lane l is M0 + imm + 16*l by construction of the instruction), so rows are PACKED at pitch 16*cpr
+// and a slice of S bytes holds any rectangle with ceil(rh*cpr/64) KiB <= S.  The global address of a chunk,
+// ((by0+r)*W + bx0)*C*4 + 16*c, is only 4-byte aligned; the last chunk of a row may run past the rectangle (never
+// read).  q -> (r, c) by a multiply-shift (exact for q*cpr < 2^16: q < 1024, cpr <= 64).
+struct Stage { int cpr, nld; float pitch, nbase; bool fits; };
+template <int C, int LDS_BYTES>
+__device__ __forceinline__ Stage plan_stage(const Extent& e) {
+    Stage s;
+    s.cpr = (e.rw * C * 4 + 15) >> 4;
+    const int n = s.cpr * e.rh;
+    s.nld = (n + 63) >> 6;
+    s.fits = e.interior && s.cpr <= 64 && s.nld * 1024 <= LDS_BYTES;
+    s.pitch = (float)(s.cpr * 16);
+    s.nbase = -((float)e.by0 * s.pitch + (float)(e.bx0 * C * 4));
+    return s;
+}
+#ifndef UH_WARP_LDS_DMA
+#define UH_WARP_LDS_DMA 1         // 0: stage through VGPRs (buffer_load_dwordx4 + ds_write_b128) -- developer A/B switch
+#endif
+template <int C, int LDS_BYTES>
+__device__ __forceinline__ void stage_dma(__amdgpu_buffer_rsrc_t rin, unsigned char* lds, int lane, const Extent& e,
+                                          const Stage& s, int rowBi) {
+    const unsigned magic = (65536u + (unsigned)s.cpr - 1u) / (unsigned)s.cpr;     // wave-uniform (SALU)
+    const unsigned n = (unsigned)(s.cpr * e.rh);
+    const unsigned base = (unsigned)e.by0 * (unsigned)rowBi + (unsigned)(e.bx0 * C * 4);
+#if UH_WARP_LDS_DMA
+#pragma unroll
+    for (int i = 0; i < LDS_BYTES / 1024; ++i) {
+        if (i < s.nld) {                                                     // wave-uniform
+            const unsigned q = (unsigned)(i * 64 + lane);
+            const unsigned r = (q * magic) >> 16;
+            const unsigned c = q - r * (unsigned)s.cpr;
+            const unsigned goff = q < n ? base + r * (unsigned)rowBi + c * 16u : 0x80000000u;   // out of range -> zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
+                                                     goff, 0, 0, 0);
+        }
+    }
+#else
+    auto goff_of = [&](int i) {
+        const unsigned q = (unsigned)(i * 64 + lane);
+        const unsigned r = (q * magic) >> 16;
+        const unsigned c = q - r * (unsigned)s.cpr;
+        return q < n ? base + r * (unsigned)rowBi + c * 16u : 0x80000000u;
+    };
     int i = 0;
-    for (; i + 4 <= r.iters; i += 4) {                      // wave-uniform trip counts
-        u32x4_t v[4];
+    for (; i + 3 <= s.nld; i += 3) {                                       // wave-uniform trip counts
+        u32x4_t v[3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, goff + (unsigned)(i + u) * gstep, 0, 0);
+        for (int u = 0; u < 3; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, goff_of(i + u), 0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4_t*>(lp + (size_t)(i + u) * 1024) = v[u];
+        for (int u = 0; u < 3; ++u) *reinterpret_cast<u32x4_t*>(lds + (i + u) * 1024 + lane * 16) = v[u];
     }
-    for (; i < r.iters; ++i) {
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rin, goff + (unsigned)i * gstep, 0, 0);
-        *reinterpret_cast<u32x4_t*>(lp + (size_t)i * 1024) = v;
+    for (; i < s.nld; ++i) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rin, goff_of(i), 0, 0);
+        *reinterpret_cast<u32x4_t*>(lds + i * 1024 + lane * 16) = v;
     }
+#endif
+}
+// the DMA's data is in LDS once the wave's vector-memory counter has drained; nothing else orders a ds_read behind it
+__device__ __forceinline__ void stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the 2x2 neighbourhood of an interior sample out of the staged rectangle: taps at o, o+pixB (same row), o+pitch ...
+template <int C>
+__device__ __forceinline__ void lds_quad(const unsigned char* lds, unsigned oa, unsigned ob, Pix<C>& Ia, Pix<C>& Ib,
+                                         Pix<C>& Ic, Pix<C>& Id) {
+    const float* pa = reinterpret_cast<const float*>(lds + oa);
+    const float* pb = reinterpret_cast<const float*>(lds + ob);
+#pragma unroll
+    for (int c = 0; c < C; ++c) { Ia.v[c] = pa[c]; Ic.v[c] = pa[C + c]; Ib.v[c] = pb[c]; Id.v[c] = pb[C + c]; }
+}
+// ... and straight from global memory (path B): two VGPR offsets, the x+1 taps use the immediate offset
+template <int C>
+__device__ __forceinline__ void global_quad(__amdgpu_buffer_rsrc_t rin, unsigned oa, unsigned ob, Pix<C>& Ia, Pix<C>& Ib,
+                                            Pix<C>& Ic, Pix<C>& Id) {
+    Ia = buf_load<C>(rin, oa, 0); Ic = buf_load<C>(rin, oa + C * 4, 0);
+    Ib = buf_load<C>(rin, ob, 0); Id = buf_load<C>(rin, ob + C * 4, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <int C, bool COND, bool SMALL>
-__global__ __launch_bounds__(256) void warp_forward_kernel(
+__global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
         const float* __restrict__ U, const float* __restrict__ theta, float* __restrict__ out,
         float* __restrict__ condition, int H, int W, int oh, int ow, float sx, float sy, int tiles_x, int tiles,
         unsigned nblk) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[STAGE_FWD ? NWAVE * LDS_PER_WAVE : 16];
+    constexpr int LDSW = UH_WARP_LDS_PER_WAVE;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[STAGE_FWD ? NWAVE * LDSW : 16];
     const int lane = threadIdx.x & 63, wave = wave_id();
-    unsigned char* lds = lds_all + (STAGE_FWD ? wave * LDS_PER_WAVE : 0);
-    const unsigned v = xcd_remap(blockIdx.x, nblk);
+    unsigned char* lds = lds_all + (STAGE_FWD ? wave * LDSW : 0);
+    float cnt = 0.f;
+    // a block walks TPB_F consecutive virtual tiles (same image, neighbouring tiles: theta and the kernel arguments
+    // stay in SGPRs / the scalar cache, and the wave's start-up cost is paid once per TPB_F tiles)
+    const unsigned v0 = xcd_remap(blockIdx.x, gridDim.x) * TPB_F;
+#pragma unroll 1
+    for (int it = 0; it < TPB_F; ++it) {
+    const unsigned v = v0 + it;
+    if (v >= nblk) break;
     const int b = v / tiles, tile = v - b * tiles;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int col = (tx * NWAVE + wave) * TW + (lane & (TW - 1));
     const int row0 = ty * TH + (lane / TW);                              // this lane's first row
-    if ((tx * NWAVE + wave) * TW >= ow) return;                          // whole wave outside (wave-uniform)
+    if ((tx * NWAVE + wave) * TW >= ow) continue;                        // whole wave outside (wave-uniform)
     const Theta th = load_theta(theta, b);
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(U + (size_t)b * H * W * C, (unsigned)(H * W * C * 4));
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out + (size_t)b * oh * ow * C, (unsigned)(oh * ow * C * 4));
@@ -175,55 +249,100 @@ __global__ __launch_bounds__(256) void warp_forward_kernel(
     const float A0 = th.a[0] * gx, A3 = th.a[3] * gx, A6 = th.a[6] * gx;
     const bool col_ok = col < ow;
     const unsigned orow = (unsigned)(ow * C * 4);
-
     const float rowf0 = (float)row0;                                     // (float)(row0 + k*WY) == rowf0 + k*WY exactly
-    Coord c[STEPS];
-#pragma unroll
-    for (int k = 0; k < STEPS; ++k) c[k] = make_coord(th, A0, A3, A6, -1.0f + sy * (rowf0 + (float)(k * WY)), g);
-    Rect r;
-    r.fits = false;
-    if constexpr (STAGE_FWD) r = wave_rect<C, STEPS>(c);
 
-    Pix<C> Ia[STEPS], Ib[STEPS], Ic[STEPS], Id[STEPS];
-    if (STAGE_FWD && r.fits) {                                          // wave-uniform
-        stage_rect<C>(rin, lds, lane, r, g.rowBi);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    Proj p[STEPS];
+    float fx[STEPS], fy[STEPS];
 #pragma unroll
-        for (int k = 0; k < STEPS; ++k) {
-            const TapOff o = staged_offsets(c[k], r.pitch, g.pixB, r.nbase);
-            Ia[k] = lds_load<C>(lds, o.oa); Ib[k] = lds_load<C>(lds, o.ob);
-            Ic[k] = lds_load<C>(lds, o.oc); Id[k] = lds_load<C>(lds, o.od);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < STEPS; ++k) {
-            const TapOff o = global_offsets<SMALL>(c[k], g);
-            Ia[k] = buf_load<C>(rin, o.oa, 0); Ib[k] = buf_load<C>(rin, o.ob, 0);
-            Ic[k] = buf_load<C>(rin, o.oc, 0); Id[k] = buf_load<C>(rin, o.od, 0);
-        }
+    for (int k = 0; k < STEPS; ++k) {
+        p[k] = project(th, A0, A3, A6, -1.0f + sy * (rowf0 + (float)(k * WY)), g);
+        fx[k] = floorf(p[k].x); fy[k] = floorf(p[k].y);                                         // (:101,103)
     }
-    float cnt = 0.f;
+    const Extent e = wave_extent<STEPS>(fx, fy, g);
+
     // Store offsets: row*orow + col*pixB, advanced by WY rows per step.  A row >= oh gives an offset >= the
     // buffer's num_records (= oh*orow), which makes the buffer unit drop the store; lanes right of the image
     // start from 2^31 and stay out of range (an image is < 2^31 bytes, check_warp_args).
     unsigned voff = col_ok ? (unsigned)row0 * orow + (unsigned)col * (C * 4) : 0x80000000u;
-#pragma unroll
-    for (int k = 0; k < STEPS; ++k) {
-        const float wa = c[k].ax1 * c[k].ay1, wb = c[k].ax1 * c[k].ay0;                         // (:134-137)
-        const float wc = c[k].ax0 * c[k].ay1, wd = c[k].ax0 * c[k].ay0;
+    auto emit = [&](int k, float ax1, float ax0, float ay1, float ay0, const Pix<C>& Ia, const Pix<C>& Ib,
+                    const Pix<C>& Ic, const Pix<C>& Id) {
+        const float wa = ax1 * ay1, wb = ax1 * ay0, wc = ax0 * ay1, wd = ax0 * ay0;             // (:134-137)
         Pix<C> o;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) o.v[ch] = blend4(wa, wb, wc, wd, Ia[k].v[ch], Ib[k].v[ch], Ic[k].v[ch], Id[k].v[ch]);
+        for (int ch = 0; ch < C; ++ch) o.v[ch] = blend4(wa, wb, wc, wd, Ia.v[ch], Ib.v[ch], Ic.v[ch], Id.v[ch]);
 #ifdef UH_DBG_NO_STORE            // developer A/B switch only: keeps the math alive, never stores
         buf_store<C, UH_WARP_STORE_AUX>(rout, o.v[0] != 12345.678f ? 0x80000000u : voff, 0, o);
 #else
         buf_store<C, UH_WARP_STORE_AUX>(rout, voff, 0, o);
 #endif
-        if (COND) cnt += (col_ok && row0 + k * WY < oh && fabsf(c[k].t) > 1e-7f) ? 1.f : 0.f;   // (:235)
+        if (COND) cnt += (col_ok && row0 + k * WY < oh && fabsf(p[k].t) > 1e-7f) ? 1.f : 0.f;   // (:235)
         voff += (unsigned)WY * orow;
+    };
+
+    if (e.interior) {                                                   // wave-uniform
+        Stage st;
+        st.fits = false;
+        if constexpr (STAGE_FWD) st = plan_stage<C, LDSW>(e);
+        float ax0[STEPS], ay0[STEPS];
+        if (STAGE_FWD && st.fits) {                                     // ---- path A
+            stage_dma<C, LDSW>(rin, lds, lane, e, st, g.rowBi);
+            unsigned oa[STEPS];
+#pragma unroll
+            for (int k = 0; k < STEPS; ++k) {                           // overlaps the DMA
+                ax0[k] = p[k].x - fx[k]; ay0[k] = p[k].y - fy[k];
+                oa[k] = (unsigned)__builtin_fmaf(fy[k], st.pitch, __builtin_fmaf(fx[k], g.pixB, st.nbase));
+            }
+            const unsigned pitchi = (unsigned)(st.cpr * 16);
+            stage_wait();
+#pragma unroll
+            for (int k = 0; k < STEPS; ++k) {
+                Pix<C> Ia, Ib, Ic, Id;
+                lds_quad<C>(lds, oa[k], oa[k] + pitchi, Ia, Ib, Ic, Id);
+                emit(k, 1.0f - ax0[k], ax0[k], 1.0f - ay0[k], ay0[k], Ia, Ib, Ic, Id);
+            }
+        } else {                                                        // ---- path B
+#pragma unroll
+            for (int k0 = 0; k0 < STEPS; k0 += BT_F) {
+                Pix<C> Ia[BT_F], Ib[BT_F], Ic[BT_F], Id[BT_F];                 // 4*BT_F gathers in flight
+#pragma unroll
+                for (int j = 0; j < BT_F; ++j) {
+                    const int k = k0 + j;
+                    unsigned oa;
+                    if constexpr (SMALL) oa = (unsigned)__builtin_fmaf(fy[k], g.rowB, fx[k] * g.pixB);
+                    else oa = (unsigned)fy[k] * (unsigned)g.rowBi + (unsigned)fx[k] * (unsigned)g.pixBi;
+                    global_quad<C>(rin, oa, oa + (unsigned)g.rowBi, Ia[j], Ib[j], Ic[j], Id[j]);
+                    ax0[k] = p[k].x - fx[k]; ay0[k] = p[k].y - fy[k];
+                }
+#pragma unroll
+                for (int j = 0; j < BT_F; ++j) {
+                    const int k = k0 + j;
+                    emit(k, 1.0f - ax0[k], ax0[k], 1.0f - ay0[k], ay0[k], Ia[j], Ib[j], Ic[j], Id[j]);
+                }
+                if (BT_F < STEPS) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {                                                            // ---- path C: clipped gather
+#pragma unroll
+        for (int k0 = 0; k0 < STEPS; k0 += BT_F) {
+            Pix<C> Ia[BT_F], Ib[BT_F], Ic[BT_F], Id[BT_F];
+            Coord c[BT_F];
+#pragma unroll
+            for (int j = 0; j < BT_F; ++j) {
+                c[j] = clip_coord(p[k0 + j], g);
+                const TapOff o = global_offsets<SMALL>(c[j], g);
+                Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
+                Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < BT_F; ++j) emit(k0 + j, c[j].ax1, c[j].ax0, c[j].ay1, c[j].ay0, Ia[j], Ib[j], Ic[j], Id[j]);
+            if (BT_F < STEPS) __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    if (TPB_F > 1) {                    // the next tile's DMA must not overtake this tile's LDS reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    }   // tiles of this block
     if (COND) {
         cnt = wave_sum(cnt);
         if (lane == 0) atomicAdd(condition, cnt);
@@ -234,18 +353,30 @@ __global__ __launch_bounds__(256) void warp_forward_kernel(
 // Backward w.r.t. theta (and optionally U).  Closed form of TF's autodiff (floor/clip/cast carry no
 // gradient; weights use the clipped corners):
 //   dx  = sum_c g_c [ ay1 (Ic - Ia) + ay0 (Id - Ib) ]      dy = sum_c g_c [ ax1 (Ib - Ia) + ax0 (Id - Ic) ]
+//   (evaluated in the algebraically equal "lerp" form, see accumulate())
 //   dxn = dx W/2, dyn = dy H/2, dxs = dxn/t, dys = dyn/t, dt = -(dxn xs + dyn ys)/t^2
 //   dTheta = [dxs; dys; dt] (3xN) . grid^T (Nx3)
 // The differences (Ic - Ia) ... are exactly 0 where the clip collapsed a corner pair, so far-field
 // samples contribute exactly nothing (the TF op order leaves f32 cancellation noise there).
 // 1/t is the refined reciprocal the sampling already produced (<= 1 ulp; the gradient is checked
-// against the f64 closed form, not bit-for-bit).
-template <int C, bool WANT_DU, bool SMALL>
-__global__ __launch_bounds__(256) void warp_backward_kernel(
+// against the f64 closed form, not bit-for-bit).  Same three paths as the forward; the per-pixel sums are
+// the same expressions on every path, so dTheta does not depend on the LDS slice size.
+//
+// PATCH mode (uh_warp_patch_backward): dOut is not a frame but dPred [B,PP], the gradient of the gray patch gather
+// (homography_model.py:263-269).  The frame gradient it stands for is dPred[e]/C on the pixels patch_idx names and 0
+// elsewhere, so (a) tiles that miss the patch rectangle are skipped (their partial is exactly the 0 the dense kernel
+// would have summed), and (b) a lane takes G = dPred[e]/C for the entry e that SHOULD sit on its pixel if the patch is
+// the rectangle anchored at patch_idx[k,0] and whose stored index confirms it.  Entries that are not at their rectangle
+// position (arbitrary gathers, duplicates) are counted and handled one by one in the finish kernel, so any index set
+// gives the gradient of uh_gray_patch_backward -> uh_warp_backward; on rectangles the sums are bit-identical to it.
+struct PatchArgs { const int* idx; int P, PP; int* confirmed; };
+template <int C, bool WANT_DU, bool SMALL, bool PATCH = false>
+__global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
         const float* __restrict__ U, const float* __restrict__ theta, const float* __restrict__ dOut,
         float* __restrict__ partial, float* __restrict__ dU,
-        int H, int W, int oh, int ow, float sx, float sy, int tiles_x, int tiles, unsigned nblk) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[STAGE_BWD ? NWAVE * LDS_PER_WAVE : 16];
+        int H, int W, int oh, int ow, float sx, float sy, int tiles_x, int tiles, unsigned nblk, PatchArgs pa) {
+    constexpr int LDSW = UH_WARP_LDS_PER_WAVE_BWD;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[STAGE_BWD ? NWAVE * LDSW : 16];
     __shared__ float red[9][NWAVE * 4];
     const int lane = threadIdx.x & 63, wave = wave_id();
     const unsigned v = xcd_remap(blockIdx.x, nblk);
@@ -256,8 +387,17 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
     float acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = 0.f;
-    if ((tx * NWAVE + wave) * TW < ow) {                                 // wave-uniform; else the wave adds 0
-        unsigned char* lds = lds_all + (STAGE_BWD ? wave * LDS_PER_WAVE : 0);
+    int nconf = 0;                                                       // PATCH: entries this lane confirmed
+    int px0 = 0, py0 = 0;                                                // PATCH: top-left pixel of the patch rectangle
+    bool live = (tx * NWAVE + wave) * TW < ow;                           // wave-uniform; else the wave adds 0
+    if constexpr (PATCH) {
+        const int o = pa.idx[(size_t)b * pa.PP];                         // uniform -> scalar load
+        py0 = o / W; px0 = o - py0 * W;
+        const int wx0 = (tx * NWAVE + wave) * TW, wy0 = ty * TH_B;
+        live = live && wx0 < px0 + pa.P && wx0 + TW > px0 && wy0 < py0 + pa.P && wy0 + TH_B > py0;
+    }
+    if (live) {
+        unsigned char* lds = lds_all + (STAGE_BWD ? wave * LDSW : 0);
         const Theta th = load_theta(theta, b);
         const __amdgpu_buffer_rsrc_t rin = make_rsrc(U + (size_t)b * H * W * C, (unsigned)(H * W * C * 4));
         const __amdgpu_buffer_rsrc_t rg = make_rsrc(dOut + (size_t)b * oh * ow * C, (unsigned)(oh * ow * C * 4));
@@ -270,7 +410,8 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
         const unsigned orow = (unsigned)(ow * C * 4);
 
         const float rowf0 = (float)row0;                                 // (float)(row0 + k*WY) == rowf0 + k*WY exactly
-        Coord c[STEPS_B];
+        Proj p[STEPS_B];
+        float fx[STEPS_B], fy[STEPS_B];
         Pix<C> G[STEPS_B];
         float gy[STEPS_B];
         // lanes past the right/bottom edge read dOut out of range (rows >= oh: offset >= num_records; columns
@@ -279,66 +420,134 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
 #pragma unroll
         for (int k = 0; k < STEPS_B; ++k) {
             gy[k] = -1.0f + sy * (rowf0 + (float)(k * WY));
-            G[k] = buf_load<C, UH_WARP_GLOAD_AUX>(rg, voff, 0);
+            if constexpr (PATCH) {
+                const int row = row0 + k * WY, u = col - px0, v = row - py0;
+                float gv = 0.f;
+                if (u >= 0 && u < pa.P && v >= 0 && v < pa.P && col < ow && row < oh) {
+                    const size_t e = (size_t)b * pa.PP + (size_t)(v * pa.P + u);
+                    if (pa.idx[e] == row * W + col) { gv = dOut[e] / (float)C; ++nconf; }
+                }
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) G[k].v[ch] = gv;
+            } else {
+                G[k] = buf_load<C, UH_WARP_GLOAD_AUX>(rg, voff, 0);
+            }
             voff += (unsigned)WY * orow;
-            c[k] = make_coord(th, A0, A3, A6, gy[k], g);
+            p[k] = project(th, A0, A3, A6, gy[k], g);
+            fx[k] = floorf(p[k].x); fy[k] = floorf(p[k].y);
         }
-        // one pixel's contribution to the nine sums (and, optionally, to dU)
-        auto accumulate = [&](int k, const Pix<C>& Ia, const Pix<C>& Ib, const Pix<C>& Ic, const Pix<C>& Id) {
+        const Extent e = wave_extent<STEPS_B>(fx, fy, g);
+        // one pixel's contribution to the nine sums
+        // hx = x1f - x0f, hy = y1f - y0f (1 for an interior sample, 0 where the clip collapsed the pair).  With
+        // ay0 = hy - ay1:  ay1 (Ic-Ia) + ay0 (Id-Ib) = ay1 [(Ic-Ia) - (Id-Ib)] + hy (Id-Ib)  -- the form used here: a
+        // sample whose y pair collapsed has Ic-Ia == Id-Ib and hy == 0 and contributes EXACTLY 0 although |ay| reaches
+        // 1e7 px there (the literal form leaves eps*|ay|*|dI| of cancellation noise per far-field sample).
+        auto accumulate = [&](int k, float ax1, float ay1, float hx, float hy, const Pix<C>& Ia, const Pix<C>& Ib,
+                              const Pix<C>& Ic, const Pix<C>& Id) {
             float dx = 0.f, dy = 0.f;
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
-                const float ex = fmaf(c[k].ay1, Ic.v[ch] - Ia.v[ch], c[k].ay0 * (Id.v[ch] - Ib.v[ch]));
-                const float ey = fmaf(c[k].ax1, Ib.v[ch] - Ia.v[ch], c[k].ax0 * (Id.v[ch] - Ic.v[ch]));
+                const float dca = Ic.v[ch] - Ia.v[ch], ddb = Id.v[ch] - Ib.v[ch];
+                const float dba = Ib.v[ch] - Ia.v[ch], ddc = Id.v[ch] - Ic.v[ch];
+                const float ex = fmaf(ay1, dca - ddb, hy * ddb);
+                const float ey = fmaf(ax1, dba - ddc, hx * ddc);
                 dx = fmaf(G[k].v[ch], ex, dx);
                 dy = fmaf(G[k].v[ch], ey, dy);
             }
-            const float rt = c[k].rt;
+            const float rt = p[k].rt;
             const float dxs = dx * halfW * rt, dys = dy * halfH * rt;
-            const float dt = -(dxs * c[k].xs + dys * c[k].ys) * rt;
+            const float dt = -(dxs * p[k].xs + dys * p[k].ys) * rt;
             acc[0] = fmaf(dxs, gx, acc[0]); acc[1] = fmaf(dxs, gy[k], acc[1]); acc[2] += dxs;
             acc[3] = fmaf(dys, gx, acc[3]); acc[4] = fmaf(dys, gy[k], acc[4]); acc[5] += dys;
             acc[6] = fmaf(dt,  gx, acc[6]); acc[7] = fmaf(dt,  gy[k], acc[7]); acc[8] += dt;
-            if (WANT_DU) {
-                const TapOff o = global_offsets<SMALL>(c[k], g);
-                const float wa = c[k].ax1 * c[k].ay1, wb = c[k].ax1 * c[k].ay0;
-                const float wc = c[k].ax0 * c[k].ay1, wd = c[k].ax0 * c[k].ay0;
+        };
+        // optional dU: scatter of the four weighted taps (the only float atomics of the library).  A sample whose x (or y)
+        // pair collapsed under the clip sends wa + wc = (ax1 + ax0) ay1 = 0 to ONE pixel: in exact arithmetic it
+        // contributes nothing, in f32 it would leave |ax| ~ 1e7 px worth of cancellation noise there -- skipped (`live`).
+        auto scatter = [&](int k, const TapOff& o, float ax1, float ax0, float ay1, float ay0, bool live) {
+            if (!live) return;
+            const float wa = ax1 * ay1, wb = ax1 * ay0, wc = ax0 * ay1, wd = ax0 * ay0;
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) {          // G is 0 for masked lanes/rows: adds 0
-                    atomicAdd(dUb + o.oa / 4 + ch, wa * G[k].v[ch]);
-                    atomicAdd(dUb + o.ob / 4 + ch, wb * G[k].v[ch]);
-                    atomicAdd(dUb + o.oc / 4 + ch, wc * G[k].v[ch]);
-                    atomicAdd(dUb + o.od / 4 + ch, wd * G[k].v[ch]);
-                }
+            for (int ch = 0; ch < C; ++ch) {          // G is 0 for masked lanes/rows: adds 0
+                atomicAdd(dUb + o.oa / 4 + ch, wa * G[k].v[ch]);
+                atomicAdd(dUb + o.ob / 4 + ch, wb * G[k].v[ch]);
+                atomicAdd(dUb + o.oc / 4 + ch, wc * G[k].v[ch]);
+                atomicAdd(dUb + o.od / 4 + ch, wd * G[k].v[ch]);
             }
         };
-        Rect r;
-        r.fits = false;
-        if constexpr (STAGE_BWD) r = wave_rect<C, STEPS_B>(c);
-        if (STAGE_BWD && r.fits) {                                      // wave-uniform
-            stage_rect<C>(rin, lds, lane, r, g.rowBi);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // one pixel at a time (LDS latency is short): only 4 taps live at once keeps the kernel under 96 VGPRs
+        if (e.interior) {                                               // wave-uniform
+            Stage st;
+            st.fits = false;
+            if constexpr (STAGE_BWD) st = plan_stage<C, LDSW>(e);
+            float ax0[STEPS_B], ay0[STEPS_B];
+            unsigned og[STEPS_B];                                       // global offset of tap (y0, x0)
 #pragma unroll
             for (int k = 0; k < STEPS_B; ++k) {
-                const TapOff o = staged_offsets(c[k], r.pitch, g.pixB, r.nbase);
-                const Pix<C> Ia = lds_load<C>(lds, o.oa), Ib = lds_load<C>(lds, o.ob);
-                const Pix<C> Ic = lds_load<C>(lds, o.oc), Id = lds_load<C>(lds, o.od);
-                accumulate(k, Ia, Ib, Ic, Id);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SMALL) og[k] = (unsigned)__builtin_fmaf(fy[k], g.rowB, fx[k] * g.pixB);
+                else og[k] = (unsigned)fy[k] * (unsigned)g.rowBi + (unsigned)fx[k] * (unsigned)g.pixBi;
             }
-        } else {
-            Pix<C> Ia[STEPS_B], Ib[STEPS_B], Ic[STEPS_B], Id[STEPS_B];         // all 16 gathers in flight before the first use
+            if (STAGE_BWD && st.fits) {                                 // ---- path A
+                stage_dma<C, LDSW>(rin, lds, lane, e, st, g.rowBi);
+                unsigned oa[STEPS_B];
 #pragma unroll
-            for (int k = 0; k < STEPS_B; ++k) {
-                const TapOff o = global_offsets<SMALL>(c[k], g);
-                Ia[k] = buf_load<C>(rin, o.oa, 0); Ib[k] = buf_load<C>(rin, o.ob, 0);
-                Ic[k] = buf_load<C>(rin, o.oc, 0); Id[k] = buf_load<C>(rin, o.od, 0);
+                for (int k = 0; k < STEPS_B; ++k) {
+                    ax0[k] = p[k].x - fx[k]; ay0[k] = p[k].y - fy[k];
+                    oa[k] = (unsigned)__builtin_fmaf(fy[k], st.pitch, __builtin_fmaf(fx[k], g.pixB, st.nbase));
+                }
+                const unsigned pitchi = (unsigned)(st.cpr * 16);
+                stage_wait();
+#pragma unroll
+                for (int k = 0; k < STEPS_B; ++k) {
+                    Pix<C> Ia, Ib, Ic, Id;
+                    lds_quad<C>(lds, oa[k], oa[k] + pitchi, Ia, Ib, Ic, Id);
+                    accumulate(k, 1.0f - ax0[k], 1.0f - ay0[k], 1.0f, 1.0f, Ia, Ib, Ic, Id);
+                }
+            } else {                                                    // ---- path B
+#pragma unroll
+                for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
+                    Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];             // 4*BT_B gathers in flight
+#pragma unroll
+                    for (int j = 0; j < BT_B; ++j) {
+                        const int k = k0 + j;
+                        global_quad<C>(rin, og[k], og[k] + (unsigned)g.rowBi, Ia[j], Ib[j], Ic[j], Id[j]);
+                        ax0[k] = p[k].x - fx[k]; ay0[k] = p[k].y - fy[k];
+                    }
+#pragma unroll
+                    for (int j = 0; j < BT_B; ++j) {
+                        const int k = k0 + j;
+                        accumulate(k, 1.0f - ax0[k], 1.0f - ay0[k], 1.0f, 1.0f, Ia[j], Ib[j], Ic[j], Id[j]);
+                    }
+                    if (BT_B < STEPS_B) __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            if (WANT_DU) {
 #pragma unroll
-            for (int k = 0; k < STEPS_B; ++k) accumulate(k, Ia[k], Ib[k], Ic[k], Id[k]);
+                for (int k = 0; k < STEPS_B; ++k) {
+                    TapOff o;
+                    o.oa = og[k]; o.ob = og[k] + (unsigned)g.rowBi; o.oc = o.oa + C * 4; o.od = o.ob + C * 4;
+                    scatter(k, o, 1.0f - ax0[k], ax0[k], 1.0f - ay0[k], ay0[k], true);
+                }
+            }
+        } else {                                                        // ---- path C: clipped gather
+#pragma unroll
+            for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
+                Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];                 // 4*BT_B gathers in flight
+                Coord c[BT_B];
+#pragma unroll
+                for (int j = 0; j < BT_B; ++j) {
+                    c[j] = clip_coord(p[k0 + j], g);
+                    const TapOff o = global_offsets<SMALL>(c[j], g);
+                    Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
+                    Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < BT_B; ++j) {
+                    accumulate(k0 + j, c[j].ax1, c[j].ay1, c[j].x1f - c[j].x0f, c[j].y1f - c[j].y0f, Ia[j], Ib[j], Ic[j], Id[j]);
+                    if (WANT_DU) scatter(k0 + j, global_offsets<SMALL>(c[j], g), c[j].ax1, c[j].ax0, c[j].ay1, c[j].ay0,
+                                         c[j].x1f != c[j].x0f && c[j].y1f != c[j].y0f);
+                }
+                if (BT_B < STEPS_B) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     // block reduction: DPP inside rows of 16 lanes, the 16 row sums of the block meet in LDS (fixed order)
@@ -347,6 +556,11 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
         const float rs = row16_sum(acc[j]);
         if ((lane & 15) == 0) red[j][wave * 4 + (lane >> 4)] = rs;
     }
+    __shared__ int redc[NWAVE];
+    if constexpr (PATCH) {
+        const int wc = (int)wave_sum((float)nconf);                      // <= 256: exact in f32
+        if (lane == 0) redc[wave] = wc;
+    }
     __syncthreads();
     if (threadIdx.x < 9) {
         const float* rr = red[threadIdx.x];
@@ -354,6 +568,9 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
 #pragma unroll
         for (int k = 0; k < NWAVE * 4; ++k) t += rr[k];
         partial[(size_t)v * 9 + threadIdx.x] = t;
+    }
+    if constexpr (PATCH) {
+        if (threadIdx.x == 0) pa.confirmed[v] = (redc[0] + redc[1]) + (redc[2] + redc[3]);
     }
 }
 
@@ -383,8 +600,15 @@ __global__ __launch_bounds__(256) void warp_forward_literal_kernel(const float* 
 // One wave per image.  The image's partials are `tiles*9` contiguous floats; lane l < 63 walks them
 // with stride 63 (= 7*9), so its accumulator index j = l % 9 never changes and every load instruction
 // is coalesced and independent of the others; the 7 lanes that share a j then meet in LDS.
+// PATCH mode adds the entries the bandwidth kernel could not take (not at their rectangle position): if the image's
+// confirmed count falls short of PP, the wave walks the PP entries and samples the stray ones itself (literal path C
+// arithmetic, f64 accumulation, fixed order).  For the dataloader's rectangles nothing is added.
+struct PatchFinish { const float* U; const float* theta; const float* dPred; const int* idx; const int* confirmed;
+                     int P, PP, H, W; float sx, sy; };
+template <int C, bool PATCH>
 __global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* __restrict__ partial,
-                                                                   float* __restrict__ dTheta, int tiles, int B) {
+                                                                   float* __restrict__ dTheta, int tiles, int B,
+                                                                   PatchFinish pf) {
     __shared__ double red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
@@ -396,12 +620,67 @@ __global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* 
         for (int e = lane; e < n; e += 63) a += (double)p[e];
     }
     red[wave][lane] = a;
+    double extra = 0.0;                                                  // lane j < 9: stray entries' share of sum j
+    if constexpr (PATCH) {
+        if (b < B) {                                                     // wave-uniform
+            int cnt = 0;
+            for (int e = lane; e < tiles; e += 64) cnt += pf.confirmed[(size_t)b * tiles + e];
+            cnt = (int)wave_sum((double)cnt);
+            if (cnt != pf.PP) {
+                const int H = pf.H, W = pf.W, P = pf.P, PP = pf.PP;
+                const int* idx = pf.idx + (size_t)b * PP;
+                const int o = idx[0];
+                const int y0 = o / W, x0 = o - y0 * W;
+                const Theta th = load_theta(pf.theta, b);
+                const SrcGeom g = make_geom<C>(W, H);
+                const float* Ub = pf.U + (size_t)b * H * W * C;
+                const float halfW = (float)W * 0.5f, halfH = (float)H * 0.5f;
+                double acc[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) acc[j] = 0.0;
+                for (int e = lane; e < PP; e += 64) {
+                    const int t = idx[e];
+                    bool direct = false;
+                    if (P > 0) {
+                        const int v = e / P, u = e - v * P;
+                        direct = (x0 + u < W) && (y0 + v < H) && t == (y0 + v) * W + (x0 + u);
+                    }
+                    if (direct) continue;
+                    const int row = t / W, col = t - row * W;
+                    const float gx = lin_at(pf.sx, col), gy = lin_at(pf.sy, row);
+                    const Coord c = make_coord(th, th.a[0] * gx, th.a[3] * gx, th.a[6] * gx, gy, g);
+                    const float gv = pf.dPred[(size_t)b * PP + e] / (float)C;
+                    const size_t ia = ((size_t)c.y0f * W + (size_t)c.x0f) * C, ib = ((size_t)c.y1f * W + (size_t)c.x0f) * C;
+                    const size_t ic = ((size_t)c.y0f * W + (size_t)c.x1f) * C, id = ((size_t)c.y1f * W + (size_t)c.x1f) * C;
+                    const float hx = c.x1f - c.x0f, hy = c.y1f - c.y0f;
+                    float dx = 0.f, dy = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                        const float Ia = Ub[ia + ch], Ib = Ub[ib + ch], Ic = Ub[ic + ch], Id = Ub[id + ch];
+                        const float dca = Ic - Ia, ddb = Id - Ib, dba = Ib - Ia, ddc = Id - Ic;
+                        dx = fmaf(gv, fmaf(c.ay1, dca - ddb, hy * ddb), dx);
+                        dy = fmaf(gv, fmaf(c.ax1, dba - ddc, hx * ddc), dy);
+                    }
+                    const float dxs = dx * halfW * c.rt, dys = dy * halfH * c.rt;
+                    const float dt = -(dxs * c.xs + dys * c.ys) * c.rt;
+                    acc[0] += (double)dxs * gx; acc[1] += (double)dxs * gy; acc[2] += (double)dxs;
+                    acc[3] += (double)dys * gx; acc[4] += (double)dys * gy; acc[5] += (double)dys;
+                    acc[6] += (double)dt * gx;  acc[7] += (double)dt * gy;  acc[8] += (double)dt;
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const double tj = wave_sum(acc[j]);
+                    if (lane == j) extra = tj;
+                }
+            }
+        }
+    }
     __syncthreads();
     if (b < B && lane < 9) {
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) t += red[wave][lane + 9 * k];
-        dTheta[(size_t)b * 9 + lane] = (float)t;
+        dTheta[(size_t)b * 9 + lane] = (float)(t + extra);
     }
 }
 
@@ -427,7 +706,7 @@ static void launch_fwd(const float* U, const float* theta, float* out, float* co
     const TileGeom g = tile_geom(oh, ow);
     const unsigned nblk = (unsigned)B * g.tiles;
     const bool sm = small_image(H, W, C);
-#define UH_FWD(COND, SM) launch_timed(UH_K_WARP_FWD, warp_forward_kernel<C, COND, SM>, dim3(nblk), dim3(256), s, U, \
+#define UH_FWD(COND, SM) launch_timed(UH_K_WARP_FWD, warp_forward_kernel<C, COND, SM>, dim3((nblk + TPB_F - 1) / TPB_F), dim3(256), s, U, \
                                      theta, out, condition, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk)
     if (condition) { if (sm) UH_FWD(true, true); else UH_FWD(true, false); }
     else           { if (sm) UH_FWD(false, true); else UH_FWD(false, false); }
@@ -464,8 +743,9 @@ static void launch_bwd(const float* U, const float* theta, const float* dOut, fl
     const TileGeom g = tile_geom(oh, ow, TH_B);
     const unsigned nblk = (unsigned)B * g.tiles;
     const bool sm = small_image(H, W, C);
-#define UH_BWD(DU, SM) launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, DU, SM>, dim3(nblk), dim3(256), s, U, \
-                                   theta, dOut, partial, dU, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk)
+#define UH_BWD(DU, SM) launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, DU, SM, false>, dim3(nblk), dim3(256), s, U, \
+                                   theta, dOut, partial, dU, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk, \
+                                   PatchArgs{nullptr, 0, 0, nullptr})
     if (dU) { if (sm) UH_BWD(true, true); else UH_BWD(true, false); }
     else    { if (sm) UH_BWD(false, true); else UH_BWD(false, false); }
 #undef UH_BWD
@@ -495,8 +775,56 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
     }
     {
         const TileGeom g = tile_geom(oh, ow, TH_B);
-        launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel, dim3((B + 3) / 4), dim3(256), s,
-                     (const float*)partial, dTheta, g.tiles, B);
+        launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel<1, false>, dim3((B + 3) / 4), dim3(256), s,
+                     (const float*)partial, dTheta, g.tiles, B, PatchFinish{});
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- sparse backward: dOut given as the gradient of the gray patch gather ----------------------------------------
+extern "C" size_t uh_warp_patch_backward_workspace_bytes(int B, int H, int W, int C) {
+    if (check_warp_args(B, H, W, C, H, W)) return 0;
+    const TileGeom g = tile_geom(H, W, TH_B);
+    return (size_t)B * g.tiles * (9 * sizeof(float) + sizeof(int));
+}
+
+template <int C>
+static void launch_patch_bwd(const float* U, const float* theta, const float* dPred, const int* idx, float* partial,
+                             int* confirmed, float* dTheta, int B, int H, int W, int P, int PP, hipStream_t s) {
+    const TileGeom g = tile_geom(H, W, TH_B);
+    const unsigned nblk = (unsigned)B * g.tiles;
+    const PatchArgs pa{idx, P, PP, confirmed};
+    if (small_image(H, W, C))
+        launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, true, true>, dim3(nblk), dim3(256), s, U, theta, dPred,
+                     partial, (float*)nullptr, H, W, H, W, lin_step(W), lin_step(H), g.tiles_x, g.tiles, nblk, pa);
+    else
+        launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, false, true>, dim3(nblk), dim3(256), s, U, theta, dPred,
+                     partial, (float*)nullptr, H, W, H, W, lin_step(W), lin_step(H), g.tiles_x, g.tiles, nblk, pa);
+    const PatchFinish pf{U, theta, dPred, idx, confirmed, P, PP, H, W, lin_step(W), lin_step(H)};
+    launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel<C, true>, dim3((B + 3) / 4), dim3(256), s,
+                 (const float*)partial, dTheta, g.tiles, B, pf);
+}
+
+extern "C" int uh_warp_patch_backward(const float* U, const float* theta, const float* dPred, const int* patch_idx,
+                                      float* dTheta, void* workspace, size_t workspace_bytes, int B, int H, int W, int C,
+                                      int PP, uh_stream_t stream) {
+    if (!U || !theta || !dPred || !patch_idx || !dTheta) return UH_E_NULL;
+    if (int e = check_warp_args(B, H, W, C, H, W)) return e;
+    if (PP <= 0) return UH_E_SHAPE;
+    if ((uint64_t)B * PP >= (1ull << 31)) return UH_E_TOO_LARGE;
+    if (!workspace || workspace_bytes < uh_warp_patch_backward_workspace_bytes(B, H, W, C)) return UH_E_WORKSPACE;
+    int P = 0;                                   // side of the square patch; 0 = no rectangle (every entry is a stray)
+    for (int q = 1; q * q <= PP; ++q) if (q * q == PP) P = q;
+    if (P > H || P > W) P = 0;
+    const TileGeom g = tile_geom(H, W, TH_B);
+    float* partial = (float*)workspace;
+    int* confirmed = (int*)(partial + (size_t)B * g.tiles * 9);
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 1: launch_patch_bwd<1>(U, theta, dPred, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
+        case 2: launch_patch_bwd<2>(U, theta, dPred, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
+        case 3: launch_patch_bwd<3>(U, theta, dPred, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
+        default: launch_patch_bwd<4>(U, theta, dPred, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
     }
     return (int)hipGetLastError();
 }

@@ -127,7 +127,8 @@ class Dataloader(object):
             raise NotImplementedError('per_image_normalize (the reference branch itself is broken, dataloader.py:180-187)')
 
     def __len__(self):
-        return len(self.names) // self.params.batch_size
+        """Batches per epoch: every pair is delivered at least once (the tail batch is completed by wrapping around)."""
+        return -(-len(self.names) // self.params.batch_size)
 
     def _load(self, i):
         pr = self.params
@@ -135,23 +136,46 @@ class Dataloader(object):
         return (_decode(os.path.join(pr.data_path, 'I', name), pr.img_h, pr.img_w),
                 _decode(os.path.join(pr.data_path, 'I_prime', name), pr.img_h, pr.img_w))
 
-    def __iter__(self):
-        pr = self.params
+    def _order(self):
         n = len(self.names)
-        order = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
-        for s in range(0, n - pr.batch_size + 1, pr.batch_size):
-            ids = order[s:s + pr.batch_size]
-            frames = list(self.pool.map(self._load, ids))
-            I8 = torch.from_numpy(np.stack([f[0] for f in frames])).to(self.device, non_blocking=True)
-            Ip8 = torch.from_numpy(np.stack([f[1] for f in frames])).to(self.device, non_blocking=True)
-            pts1 = torch.from_numpy(self.pts1[ids].astype(np.float32))
-            aug = sample_augmentation(len(ids), pr.mode, pr.do_augment, self.gen) if pr.do_augment > 0 else None
-            normalize = 'normalize' in pr.augment_list
-            batch = prepare_inputs(I8, Ip8, pts1, pr.patch_size, aug,
-                                   MEAN_I if normalize else (0., 0., 0.), STD_I if normalize else (1., 1., 1.))
-            batch['gt'] = (torch.from_numpy(self.gt[ids].astype(np.float32)).to(self.device)
-                           if self.gt is not None else torch.zeros(len(ids), 8, device=self.device))
-            yield batch
+        return torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
+
+    def _batch(self, ids):
+        pr = self.params
+        frames = list(self.pool.map(self._load, ids))
+        I8 = torch.from_numpy(np.stack([f[0] for f in frames])).to(self.device, non_blocking=True)
+        Ip8 = torch.from_numpy(np.stack([f[1] for f in frames])).to(self.device, non_blocking=True)
+        pts1 = torch.from_numpy(self.pts1[ids].astype(np.float32))
+        aug = sample_augmentation(len(ids), pr.mode, pr.do_augment, self.gen) if pr.do_augment > 0 else None
+        normalize = 'normalize' in pr.augment_list
+        batch = prepare_inputs(I8, Ip8, pts1, pr.patch_size, aug,
+                               MEAN_I if normalize else (0., 0., 0.), STD_I if normalize else (1., 1., 1.))
+        batch['gt'] = (torch.from_numpy(self.gt[ids].astype(np.float32)).to(self.device)
+                       if self.gt is not None else torch.zeros(len(ids), 8, device=self.device))
+        return batch
+
+    def stream(self):
+        """Endless stream of full batches, the reference's tf.train.(shuffle_)batch queue (dataloader.py:255-262): the
+        index list is cycled epoch after epoch (re-shuffled each time), so NO pair is ever dropped and a batch may
+        straddle two epochs.  Raises instead of spinning when there is nothing to deliver."""
+        B = self.params.batch_size
+        if len(self.names) == 0:
+            raise ValueError('Dataloader: %s lists no pairs' % self.params.filenames_file)
+        if B <= 0:
+            raise ValueError('Dataloader: batch_size must be positive')
+        pending = []
+        while True:
+            while len(pending) < B:
+                pending.extend(self._order())
+            ids, pending = pending[:B], pending[B:]
+            yield self._batch(ids)
+
+    def __iter__(self):
+        """One epoch = ceil(n / batch_size) full batches; the last one is completed with the first pairs of the next
+        pass, so every pair is seen (the round-1 loader dropped the remainder and yielded nothing for n < batch_size)."""
+        it = self.stream()
+        for _ in range(len(self)):
+            yield next(it)
 
 
 def write_dataset(data_path, I_u8, I_prime_u8, pts1, gt, prefix='', fmt='png'):

@@ -258,11 +258,7 @@ def train(args):
                                         augment_list=args.augment_list, do_augment=args.do_augment)
         loader = uh_data.Dataloader(prm, shuffle=True, device=device, seed=args.seed * 1000 + rank)
 
-        def forever():
-            while True:
-                for b in loader:
-                    yield b
-        disk = forever()
+        disk = loader.stream()                 # endless, never drops a pair, raises on an empty list
     t0 = time.time()
     for step in range(start_step, start_step + args.num_total_steps):
         if disk is not None:
@@ -301,8 +297,11 @@ class TestHomography(object):
         net = step_fn.net if step_fn is not None else VGGRegressor(args.patch_size, args.use_batch_norm).to(device)
         if step_fn is None:
             _, ckpt = _ckpt_path(args)
-            if os.path.exists(ckpt):
-                net.load_state_dict(torch.load(ckpt, map_location=device)['net'])
+            if not os.path.exists(ckpt):
+                # the reference fails on restore (saver.restore, :427-431); statistics of a random net are not results
+                raise FileNotFoundError('TestHomography: no checkpoint at %s (train first, or pass a TrainStep)' % ckpt)
+            net.load_state_dict(torch.load(ckpt, map_location=device)['net'])
+            net = net.to(memory_format=torch.channels_last)
         self.net = net
         self.device = device
         self.params = homography_model_params(
@@ -322,12 +321,12 @@ class TestHomography(object):
                                             patch_size=a.patch_size, augment_list=a.augment_list, do_augment=a.do_augment)
             loader = uh_data.Dataloader(prm, shuffle=False, device=self.device, seed=a.seed)
             num_test_data = len(loader.names)
+            if 0 < num_test_data < a.batch_size:                          # test_batch_size = min(n, batch_size) (:136)
+                loader.params = prm._replace(batch_size=num_test_data)
+                self.params = self.params._replace(batch_size=num_test_data)
+                a = argparse.Namespace(**dict(vars(a), batch_size=num_test_data))
 
-            def forever():
-                while True:
-                    for b in loader:
-                        yield b
-            disk = forever()
+            disk = loader.stream()             # shuffle=False: consecutive batches walk the list in order, wrapping
         steps_per_epoch = int(np.ceil(num_test_data / a.batch_size))
         num_steps = 3 * steps_per_epoch                                   # (:400-401)
         per_pair, total_fail, total_bounded = [], 0.0, 0.0

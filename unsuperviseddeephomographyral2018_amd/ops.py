@@ -202,6 +202,55 @@ class _GrayPatch(torch.autograd.Function):
         return dW, None, None
 
 
+class _WarpGather(torch.autograd.Function):
+    """transform() of the reference as ONE autograd node: warped = transformer(U, theta, (H, W)); pred_I2 = gather(gray(
+    warped), patch_indices)  (homography_model.py:257-269).  The forward materialises `warped` exactly like the reference
+    (uh_warp_forward + uh_gray_patch_forward).  The backward does NOT build the 79 %-zero [B,H,W,C] gradient frame of
+    tf.gather's scatter and stream it through the dense warp backward: uh_warp_patch_backward takes dPred [B,PP] and
+    the indices, skips the tiles outside the patch rectangle and is bit-identical to the dense chain on rectangles."""
+
+    @staticmethod
+    def forward(ctx, U, theta, patch_idx, patch_size):
+        lib = _lib.load()
+        U = _f32(U, 'U'); theta9 = _f32(theta, 'theta').reshape(-1, 9)
+        B, H, W, Cc = U.shape
+        if patch_idx.dtype != torch.int32 or not patch_idx.is_cuda:
+            raise _lib.UHError('patch_indices must be an int32 tensor on the HIP device')
+        idx = patch_idx.contiguous().reshape(B, -1)
+        PP = idx.shape[1]
+        warped = torch.empty((B, H, W, Cc), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_warp_forward(_ptr(U), _ptr(theta9), _ptr(warped), None, B, H, W, Cc, H, W, _stream()),
+                   'uh_warp_forward')
+        pred = torch.empty((B, PP), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_gray_patch_forward(_ptr(warped), _ptr(idx), _ptr(pred), B, H, W, Cc, PP, _stream()),
+                   'uh_gray_patch_forward')
+        ctx.save_for_backward(U, theta9, idx)
+        ctx.dims = (B, H, W, Cc, PP)
+        ctx.theta_shape = theta.shape
+        ctx.mark_non_differentiable(warped)
+        return warped, pred.reshape(B, patch_size, patch_size, 1)
+
+    @staticmethod
+    def backward(ctx, dWarped, dPred):
+        lib = _lib.load()
+        U, theta9, idx = ctx.saved_tensors
+        B, H, W, Cc, PP = ctx.dims
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None
+        dPred = _f32(dPred, 'dPred')
+        dT = torch.empty((B, 9), dtype=torch.float32, device=U.device)
+        nbytes = lib.uh_warp_patch_backward_workspace_bytes(B, H, W, Cc)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_warp_patch_backward(_ptr(U), _ptr(theta9), _ptr(dPred), _ptr(idx), _ptr(dT), _ptr(ws), nbytes,
+                                              B, H, W, Cc, PP, _stream()), 'uh_warp_patch_backward')
+        return None, dT.reshape(ctx.theta_shape), None, None
+
+
+def warp_gather(U, theta, patch_indices, patch_size):
+    """-> (warped [B,H,W,C] (no gradient), pred_I2 [B,P,P,1]); d pred_I2 / d theta by the sparse warp backward."""
+    return _WarpGather.apply(U, theta, patch_indices, patch_size)
+
+
 def gray_patch_gather(warped, patch_indices, patch_size):
     """reduce_mean(axis=3) + flat gather (homography_model.py:263-269) -> [B,P,P,1]."""
     return _GrayPatch.apply(warped, patch_indices, patch_size)
@@ -374,7 +423,12 @@ class _PhotometricTail(torch.autograd.Function):
                                    plan._Mh.ctypes.data_as(C.c_void_p), plan._Mih.ctypes.data_as(C.c_void_p), _ptr(Hm),
                                    _ptr(pred), _ptr(loss), _ptr(dh4p), C.c_void_p(plan.ws.data_ptr()), plan.nbytes,
                                    _stream()), 'uh_tail_run')
-        ctx.dh4p = dh4p
+        # The plan's buffers are overwritten by the NEXT run of the same plan (TailPlan.get caches per shape, so a second
+        # tower or a gradient-accumulation micro-step shares it).  What autograd and the caller keep must not alias
+        # them: hand out copies (dh4p, loss, H are tiny; pred is B*P*P floats).  plan.warped stays plan-owned and is
+        # documented as valid until the next run.
+        ctx.dh4p = dh4p.clone() if dh4p is not None else None
+        pred = pred.clone(); Hm = Hm.clone(); loss = loss.clone()
         ctx.mark_non_differentiable(pred, Hm)
         return loss[0], pred, Hm
 
