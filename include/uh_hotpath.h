@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define UH_ABI_VERSION 1
+#define UH_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define UH_API __attribute__((visibility("default")))
@@ -149,14 +149,25 @@ UH_API int uh_prepare_inputs(const unsigned char* I_u8, const unsigned char* Ipr
                       float* I_aug, float* Iprime_aug, float* I1, float* I2, float* I1_aug, float* I2_aug,
                       int* patch_idx, int B, int H, int W, int P, uh_stream_t stream);
 
-/* ---- all photometric losses in one pass ---------------------------------------------
- * pred, target [B,P,P] (one channel)  ->  out6[6] (device):
+/* ---- all photometric losses in one pass, and the gradient of the trained one ----------------
+ * pred, target [B,P,P] (one channel)  ->  out16[16] (device):
  *   [0] rec_loss  [1] ssim_loss  [2] l1_loss  [3] l1_smooth_loss  [4] ncc_loss        homography_model.py:136-166,286-352
  *   [5] h_loss = sqrt(mean((h4p - gt)^2)) over [B,8] when h4p/gt are given (both or neither), else 0      :288
- * Forward values only (the stop_gradient monitors the reference fetches every step).                            */
+ *   [6..12] the raw sums behind them: |d|, d^2, smooth-l1, x^2, y^2, x*y, ssim term (x = pred, y = target, d = x - y);
+ *   [13..15] reserved (0).                                                                                          */
 UH_API size_t uh_patch_losses_workspace_bytes(int B, int P);
 UH_API int uh_patch_losses_forward(const float* pred, const float* target, const float* h4p, const float* gt,
-                            float* out6, void* workspace, size_t workspace_bytes, int B, int P, uh_stream_t stream);
+                            float* out16, void* workspace, size_t workspace_bytes, int B, int P, uh_stream_t stream);
+/* dPred [B,P,P] = dLoss[0] * d loss_kind / d pred  (TF autodiff of the loss expressions above; dLoss is a device scalar;
+ * stats16 is the out16 of uh_patch_losses_forward on the same pred / target: it carries the global norms rec and ncc
+ * divide by).  kind = index of the loss in out16.                                                                   */
+#define UH_LOSS_REC        0
+#define UH_LOSS_SSIM       1
+#define UH_LOSS_L1         2
+#define UH_LOSS_L1_SMOOTH  3
+#define UH_LOSS_NCC        4
+UH_API int uh_patch_loss_backward(int kind, const float* pred, const float* target, const float* stats16,
+                           const float* dLoss, float* dPred, int B, int P, uh_stream_t stream);
 
 /* ---- fused patch path ---------------------------------------------------------
  * For the P x P loss patch only: sample -> gray -> |pred - I2| -> loss, and d loss/d theta for
@@ -227,7 +238,8 @@ UH_API int    uh_bias_relu_pool_backward(const float* y, const float* gpooled, f
 #define UH_K_PREPARE       13
 #define UH_K_EPI_FWD       14
 #define UH_K_EPI_BWD       15
-#define UH_K_COUNT         16
+#define UH_K_LOSS_BWD      16
+#define UH_K_COUNT         17
 /* on = 0: off; 1: time every kernel; otherwise a mask: bit (k + 1) set = time kernel UH_K_k only (timing a dispatch
  * costs a few us of pipeline bubble, so a throughput run times just the kernels it reports).  Returns the previous
  * on/off state; resets the counters.                                                                              */

@@ -129,6 +129,55 @@ def photometric_l1(I, I2, pts1, pred_h4p, patch_indices, img_w, img_h, patch_siz
     return (pred_I2 - I2).abs().mean(), pred_I2, warped, theta, H_mat
 
 
+# ---- the photometric losses, op for op (homography_model.py:136-166, 298-352) ----------------------------------
+def _L1_smooth_loss(x, y):
+    abs_diff = torch.abs(x - y)
+    return torch.mean(torch.where(abs_diff < 1, 0.5 * abs_diff * abs_diff, abs_diff - 0.5))
+
+
+def _SSIM_loss(x, y, size=3):
+    C1 = 0.01 ** 2
+    C2 = 0.03 ** 2
+    x = x.permute(0, 3, 1, 2); y = y.permute(0, 3, 1, 2)                       # slim.avg_pool2d is NHWC; torch is NCHW
+    pool = lambda v: torch.nn.functional.avg_pool2d(v, size, 1)                # 'VALID'
+    mu_x = pool(x); mu_y = pool(y)
+    sigma_x = pool(x ** 2) - mu_x ** 2
+    sigma_y = pool(y ** 2) - mu_y ** 2
+    sigma_xy = pool(x * y) - mu_x * mu_y
+    SSIM_n = (2 * mu_x * mu_y + C1) * (2 * sigma_xy + C2)
+    SSIM_d = (mu_x ** 2 + mu_y ** 2 + C1) * (sigma_x + sigma_y + C2)
+    SSIM = SSIM_n / SSIM_d
+    return torch.clamp((1 - SSIM) / 2, 0, 1)
+
+
+def _NCC_loss(x, y):
+    len_x = torch.sqrt(torch.sum(x * x))
+    len_y = torch.sqrt(torch.sum(y * y))
+    return torch.sqrt(torch.sum((x / len_x - y / len_y) ** 2))
+
+
+def patch_loss(loss_type, pred_I2, I2):
+    """The loss tensor build_losses() trains on for `loss_type` (everything but h_loss)."""
+    if loss_type == 'rec_loss':
+        return torch.sqrt(torch.mean((pred_I2 - I2) ** 2))                     # :303
+    if loss_type == 'ssim_loss':
+        return torch.mean(_SSIM_loss(pred_I2, I2))                             # :314
+    if loss_type == 'l1_loss':
+        return torch.mean(torch.abs(pred_I2 - I2))                             # :328
+    if loss_type == 'l1_smooth_loss':
+        return _L1_smooth_loss(pred_I2, I2)                                    # :339
+    if loss_type == 'ncc_loss':
+        return _NCC_loss(I2, pred_I2)                                          # :350
+    raise ValueError(loss_type)
+
+
+def photometric_loss(loss_type, I, I2, pts1, pred_h4p, patch_indices, img_w, img_h, patch_size):
+    """solve_DLT -> transform -> the `loss_type` branch of build_losses."""
+    H_mat = solve_DLT(pts1, pred_h4p)
+    pred_I2, warped, theta = transform(I, H_mat, patch_indices, img_w, img_h, patch_size)
+    return patch_loss(loss_type, pred_I2, I2), pred_I2
+
+
 def train_step_cpu(net, opt, batch, img_w, img_h, patch_size, loss_type='l1_loss'):
     """One full reference-equivalent train step on CPU tensors (VGG from the product package is plain
     torch and runs on CPU; the hot path is the op graph above)."""

@@ -63,6 +63,10 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert lib.uh_patch_losses_forward(one, one, None, None, one, one, 1 << 20, 2, 2, None) == -2   # P < 3 (3x3 SSIM window)
     assert lib.uh_patch_losses_forward(one, one, None, None, one, None, 0, 2, 16, None) == -4
     assert lib.uh_patch_losses_workspace_bytes(64, 128) == 64 * 64 * 7 * 4
+    assert lib.uh_patch_loss_backward(7, one, one, one, one, one, 2, 16, None) == -2             # unknown loss kind
+    assert lib.uh_patch_loss_backward(1, one, one, None, one, one, 2, 16, None) == -1
+    assert lib.uh_warp_patch_backward(one, one, one, one, one, None, 0, 2, 16, 16, 3, 64, None) == -4
+    assert lib.uh_warp_patch_backward_workspace_bytes(64, 240, 320, 3) == 64 * 5 * 15 * (9 * 4 + 4)
     args13 = [one] * 13
     assert lib.uh_prepare_inputs(*args13, 0, 8, 8, 4, None) == -2
     assert lib.uh_prepare_inputs(*args13, 2, 8, 8, 16, None) == -2                                  # patch larger than frame
@@ -78,7 +82,8 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert lib.uh_tail_create(C.byref(plan), 4, 60, 80, 5, 32, 0) == -3
     assert lib.uh_tail_create(C.byref(plan), 4, 60, 80, 3, 32, _lib.UH_TAIL_GRAPH) == 0 and plan.value
     nb_full = lib.uh_tail_workspace_bytes(plan)
-    assert nb_full >= 2 * 4 * 60 * 80 * 3 * 4 and lib.uh_tail_warped_offset(plan) % 256 == 0
+    # one full frame (warped); the gradient frame is gone: the backward takes dPred directly (uh_warp_patch_backward)
+    assert 4 * 60 * 80 * 3 * 4 <= nb_full < 2 * 4 * 60 * 80 * 3 * 4 and lib.uh_tail_warped_offset(plan) % 256 == 0
     assert lib.uh_tail_run(plan, *([one] * 11), one, nb_full - 1, None) == -4
     assert lib.uh_tail_run(plan, None, *([one] * 10), one, nb_full, None) == -1
     lib.uh_tail_destroy(plan)

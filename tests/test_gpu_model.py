@@ -38,7 +38,7 @@ def test_call_surface_and_gradients(pkg, dev, loss_type):
     hm, synthetic, _ = pkg
     batch = synthetic.make_batch(B, H, W, P, RHO, seed=1, device=dev)
     torch.manual_seed(0)
-    m = hm.HomographyModel(params(hm, 'train', B, P, W, H, loss_type), *synthetic.model_args(batch))
+    m = hm.HomographyModel(params(hm, 'train', B, P, W, H, loss_type), *synthetic.model_args(batch), solve_f64=True)
     for attr in ('pred_h4p', 'H_mat', 'pred_I2', 'h_loss', 'rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss',
                  'ncc_loss', 'I', 'I_prime', 'I1', 'I2', 'I1_aug', 'I2_aug', 'pts_1', 'gt', 'model_input'):
         assert hasattr(m, attr), attr
@@ -49,9 +49,36 @@ def test_call_surface_and_gradients(pkg, dev, loss_type):
         assert v.requires_grad == (n == loss_type), (n, loss_type)       # others are stop_gradient monitors
     net = hm.get_variables()
     net.zero_grad(set_to_none=True)
+    (g_h4p,) = torch.autograd.grad(m.loss, m.pred_h4p, retain_graph=True)
     m.loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     assert float(net.fc2.weight.grad.abs().sum()) > 0
+    # gradient VALUES: d loss / d pred_h4p through DLT -> warp -> gather -> loss (all HIP) against f64 autograd of the
+    # reference-equivalent op graph on CPU (oracle/hotpath_torch.py) at the same pred_h4p.  cond(A) of the DLT system is
+    # ~1e7, so an f32 solve moves theta by ~1e-3 relative; the tolerance is relative to the gradient's largest entry.
+    h = m.pred_h4p.detach().cpu().double().requires_grad_(True)
+    cpu = {k: v.detach().cpu() for k, v in batch.items()}
+    if loss_type == 'h_loss':
+        ref_loss = torch.sqrt(torch.mean((h - cpu['gt'].double()) ** 2))
+    else:
+        ref_loss, _ = OT.photometric_loss(loss_type, cpu['I_aug'].double(), cpu['I2_aug'].double(), cpu['pts1'].double(), h,
+                                          cpu['patch_indices'], W, H, P)
+    ref_loss.backward()
+    assert abs(float(m.loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss))), (float(m.loss), float(ref_loss))
+    err = (g_h4p.cpu().double() - h.grad).abs().max() / h.grad.abs().max()
+    assert float(err) < 5e-3, (loss_type, float(err))
+    # ... and the fused patch path (no warped frame) gives the same loss and gradient
+    torch.manual_seed(0)
+    mf = hm.HomographyModel(params(hm, 'train', B, P, W, H, loss_type), *synthetic.model_args(batch),
+                            reuse_variables=True, fused_patch=True, solve_f64=True)
+    if loss_type != 'h_loss':
+        hf = mf.pred_h4p.detach().cpu().double().requires_grad_(True)
+        lf, _ = OT.photometric_loss(loss_type, cpu['I_aug'].double(), cpu['I2_aug'].double(), cpu['pts1'].double(), hf,
+                                    cpu['patch_indices'], W, H, P)
+        lf.backward()
+        (gf,) = torch.autograd.grad(mf.loss, mf.pred_h4p)
+        assert abs(float(mf.loss) - float(lf)) <= 1e-4 * max(1.0, abs(float(lf)))
+        assert float((gf.cpu().double() - hf.grad).abs().max() / hf.grad.abs().max()) < 5e-3, loss_type
     # second tower shares the variables
     m2 = hm.HomographyModel(params(hm, 'train', B, P, W, H, loss_type), *synthetic.model_args(batch),
                             reuse_variables=True, model_index=1)

@@ -422,6 +422,34 @@ def test_patch_losses_vs_oracle(ops, dev, B, P):
     assert np.array_equal(got2[:5], got[:5]) and got2[5] == 0.0
 
 
+@pytest.mark.parametrize('kind', ['rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss'])
+@pytest.mark.parametrize('B,P', [(3, 16), (2, 128), (5, 37)])
+def test_patch_loss_backward_vs_torch_autograd(ops, dev, B, P, kind):
+    """uh_patch_loss_backward (d loss / d pred_I2 of the loss being trained on) against torch-CPU f64 autograd of the
+    reference's loss expressions (oracle/hotpath_torch.py: homography_model.py:136-166, 298-352), with an incoming
+    gradient != 1; P = 37 is not a multiple of the 16x16 SSIM tile."""
+    from oracle import hotpath_torch as OT
+    rs = np.random.RandomState(B * 100 + P + len(kind))
+    x = (rs.randn(B, P, P, 1) * 1.5).astype(np.float32)
+    y = (x + rs.randn(B, P, P, 1) * rs.choice([0.05, 0.8, 2.0], size=(B, 1, 1, 1))).astype(np.float32)
+    xt = T(x, dev).requires_grad_(True)
+    out = ops.patch_losses(xt, T(y, dev), train=kind)
+    k = {'rec_loss': 0, 'ssim_loss': 1, 'l1_loss': 2, 'l1_smooth_loss': 3, 'ncc_loss': 4}[kind]
+    (1.7 * out[k]).backward()
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    lr = OT.patch_loss(kind, xr, torch.from_numpy(y).double())
+    (1.7 * lr).backward()
+    assert abs(float(out[k]) - float(lr)) <= 1e-5 * max(1.0, abs(float(lr)))
+    got, ref = xt.grad.cpu().numpy(), xr.grad.numpy()
+    assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max(), (kind, np.abs(got - ref).max(), np.abs(ref).max())
+    # monitors carry no gradient: training on one loss must not leak through another element
+    xt2 = T(x, dev).requires_grad_(True)
+    out2 = ops.patch_losses(xt2, T(y, dev), train=kind)
+    other = (k + 1) % 5
+    out2[other].backward()
+    assert float(xt2.grad.abs().max()) == 0.0
+
+
 def test_gray_patch_duplicate_indices(ops, dev):
     """patch_indices with collisions: backward must accumulate (gather grad = scatter-ADD)."""
     w = torch.randn(1, 4, 4, 3, device=dev, requires_grad=True)
@@ -474,7 +502,8 @@ def test_gray_patch_backward_index_sets(ops, dev, case):
 def test_warp_patch_backward_equals_dense_chain(ops, dev, case):
     """uh_warp_patch_backward (sparse: dPred + indices, tiles outside the patch rectangle skipped, stray entries added one
     by one) against the dense chain it replaces, uh_gray_patch_backward -> uh_warp_backward, on the same index sets as
-    above: bit-identical on true rectangles, <= 1e-5 relative where stray entries take the f64 fix-up path."""
+    above: bit-identical on true rectangles, <= 1e-5 relative where stray entries take the f64 fix-up path (a rectangle
+    whose rows run past the right edge has stray entries: x0 + u >= W is not a pixel of that row)."""
     rs = np.random.RandomState(hash(case) % 1000 + 7)
     B, H, W, C, P = 3, 60, 92, 3, 24
     PP = P * P
@@ -512,7 +541,7 @@ def test_warp_patch_backward_equals_dense_chain(ops, dev, case):
     dT = torch.full((B, 9), 7.0, device=dev)
     _lib.check(lib.uh_warp_patch_backward(p(U), p(tth), p(dP), p(tidx), p(dT), p(ws2), nb2, B, H, W, C, PP, st), 'patch_bwd')
     a, b = dT.cpu().numpy(), dT_dense.cpu().numpy()
-    if case in ('rect', 'rect_wrapping_row'):
+    if case == 'rect':                       # every entry at its rectangle position: same tiles, same order, same bits
         assert np.array_equal(a, b)
     else:
         for k in range(B):

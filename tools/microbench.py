@@ -51,6 +51,19 @@ def run(B, H, W, P, rho, iters, dev):
     theta = theta.detach()
     if os.environ.get('UH_IDENTITY_THETA'):
         theta = torch.eye(3, device=dev).reshape(1, 9).repeat(B, 1).contiguous()
+    kind = os.environ.get('UH_THETA_KIND')
+    if kind:                                   # controlled footprints: which part of the law costs what
+        import math
+        def T9(m):
+            return torch.tensor(m, dtype=torch.float32, device=dev).reshape(1, 9).repeat(B, 1).contiguous()
+        rot = lambda deg: [[math.cos(math.radians(deg)), -math.sin(math.radians(deg)), 0],
+                           [math.sin(math.radians(deg)), math.cos(math.radians(deg)), 0], [0, 0, 1]]
+        theta = {'shift': T9([[1, 0, 0.0371], [0, 1, -0.0213], [0, 0, 1]]),
+                 'rot5': T9(rot(5)), 'rot15': T9(rot(15)), 'rot45': T9(rot(45)),
+                 'zoomin': T9([[0.8, 0, 0], [0, 0.8, 0], [0, 0, 1]]),
+                 'zoomout': T9([[1.25, 0, 0], [0, 1.25, 0], [0, 0, 1]]),
+                 'zoomout2': T9([[2.0, 0, 0], [0, 2.0, 0], [0, 0, 1]]),
+                 'persp': T9([[1, 0, 0], [0, 1, 0], [0.15, 0.1, 1]])}[kind]
     dOut = torch.randn_like(U)
     bytes_fwd = 2 * B * H * W * 3 * 4
     res = {'B': B, 'H': H, 'W': W, 'alg_MB_fwd': bytes_fwd / 1e6}
@@ -108,7 +121,7 @@ def main():
     for cfg in args.configs.split(';'):
         B, H, W, P, rho = (int(v) for v in cfg.split(','))
         r = run(B, H, W, P, rho, args.iters, dev)
-        r['lib'] = os.path.basename(_lib.LIB_PATH); r['identity'] = bool(os.environ.get('UH_IDENTITY_THETA'))
+        r['lib'] = os.path.basename(_lib.LIB_PATH); r['identity'] = bool(os.environ.get('UH_IDENTITY_THETA')); r['theta_kind'] = os.environ.get('UH_THETA_KIND', '')
         print(json.dumps(r), flush=True)
 
 

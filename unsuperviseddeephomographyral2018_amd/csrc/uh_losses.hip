@@ -9,9 +9,10 @@
 //   l1_loss        = mean(|x - y|)                                           :328
 //   l1_smooth_loss = mean(|d| < 1 ? 0.5 d^2 : |d| - 0.5)                     :136-139
 //   ncc_loss       = sqrt(sum((y/|y| - x/|x|)^2)) = sqrt(2 - 2 <x,y>/(|x||y|))   :161-166 (called as _NCC_loss(I2, pred))
-// with x = pred_I2, y = I2_aug, both [B,P,P] (one channel).  Forward values only: the gradient-carrying loss of
-// the hot path (l1_loss) has its own kernels; the other losses keep a torch-autograd path when they are trained on.
-// HBM-bound and tiny (2*B*P*P*4 bytes = 8.4 MB at B=64): the point is the launch count.
+// with x = pred_I2, y = I2_aug, both [B,P,P] (one channel), and -- for whichever of them is being trained on --
+// d loss / d pred_I2 in one more pass (uh_patch_loss_backward; the reference gets it from TF autodiff of
+// homography_model.py:136-166,298-352).  HBM-bound and tiny (2*B*P*P*4 bytes = 8.4 MB at B=64): the point is the
+// launch count.
 #include "uh_device.h"
 #include "uh_host.h"
 
@@ -105,6 +106,117 @@ __global__ __launch_bounds__(256) void patch_losses_finish_kernel(const float* _
         const double c = den > 0.0 ? s[5] / den : 0.0;          // x or y identically 0: the reference yields NaN; monitor only
         out[4] = (float)sqrt(fmax(0.0, 2.0 - 2.0 * c));
         out[5] = h4p ? (float)sqrt(s[NLS] / (double)nh) : 0.f;
+        // raw sums for uh_patch_loss_backward (the global norms of rec / ncc): |d|, d^2, smooth, x^2, y^2, xy, ssim
+#pragma unroll
+        for (int k = 0; k < NLS; ++k) out[6 + k] = (float)s[k];
+        out[13] = 0.f; out[14] = 0.f; out[15] = 0.f;
+    }
+}
+
+// ---- gradients -------------------------------------------------------------------------------------------------
+// Point-wise losses: dPred_p = dLoss * f(x_p, y_p; global sums).  N = B*P*P.
+//   rec    : d / (N rec)                      rec = sqrt(mean d^2)                              (:303)
+//   l1     : sign(d) / N                                                                        (:328)
+//   smooth : (|d| < 1 ? d : sign(d)) / N                                                        (:136-139)
+//   ncc    : -(1/ncc) [ (y/|y| - x/|x|)/|x| - x (<x,y>/|y| - |x|)/|x|^3 ]                        (:161-166)
+// A zero norm (rec == 0, ncc == 0, |x| == 0) is 0/0 in the reference's autodiff; 0 is written here.
+template <int KIND>
+__global__ __launch_bounds__(256) void patch_loss_backward_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                                  const float* __restrict__ stats,
+                                                                  const float* __restrict__ dLoss,
+                                                                  float* __restrict__ dX, size_t n) {
+    const float g = dLoss[0], inv_n = 1.0f / (float)n;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (KIND == UH_LOSS_REC) {
+        const float rec = stats[0];
+        c0 = rec > 0.f ? g * inv_n / rec : 0.f;
+    } else if (KIND == UH_LOSS_NCC) {
+        const float lx = sqrtf(stats[9]), ly = sqrtf(stats[10]), sxy = stats[11], ncc = stats[4];
+        if (lx > 0.f && ly > 0.f && ncc > 0.f) {
+            const float k = -g / ncc;
+            c0 = k / (lx * ly);                                   // * y
+            c1 = -k / (lx * lx) - k * (sxy / ly - lx) / (lx * lx * lx);   // * x
+        }
+    } else {
+        c2 = g * inv_n;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = X[i], y = Y[i], d = x - y;
+        float r;
+        if (KIND == UH_LOSS_REC) r = c0 * d;
+        else if (KIND == UH_LOSS_NCC) r = c0 * y + c1 * x;
+        else if (KIND == UH_LOSS_L1) r = d > 0.f ? c2 : (d < 0.f ? -c2 : 0.f);
+        else r = fabsf(d) < 1.0f ? c2 * d : (d > 0.f ? c2 : -c2);
+        dX[i] = r;
+    }
+}
+
+// SSIM: loss = (1/Ns) sum_w clip((1 - SSIM_w)/2, 0, 1) over the VALID 3x3 windows w.  With the window sums,
+//   dSSIM_w/dx_p = alpha_w + beta_w x_p + gamma_w y_p     for every pixel p of w        (derivation in DESIGN.md 3.5)
+//   gamma = (2/9) A1/(B1 B2)    beta = -(2/9) SSIM/B2
+//   alpha = (2/9) [ mu_y (A2 - A1)/(B1 B2) - SSIM mu_x (1/B1 - 1/B2) ]
+// and a pixel belongs to up to 9 windows.  One block = one 16x16 pixel tile of one image: the 20x20 pixel halo and
+// the 18x18 window coefficients (already scaled by -dLoss/(2 Ns) and zeroed where the clip is inactive or the window
+// does not exist) live in LDS.
+constexpr int ST = 16;
+__global__ __launch_bounds__(256) void patch_ssim_backward_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                                  const float* __restrict__ dLoss,
+                                                                  float* __restrict__ dX, int P, int tiles_1d, float scale) {
+    __shared__ float xs[ST + 4][ST + 5], ys[ST + 4][ST + 5];
+    __shared__ float ca[ST + 2][ST + 3], cb[ST + 2][ST + 3], cg[ST + 2][ST + 3];
+    const int b = blockIdx.x / (tiles_1d * tiles_1d), t = blockIdx.x - b * tiles_1d * tiles_1d;
+    const int ti = (t / tiles_1d) * ST, tj = (t - (t / tiles_1d) * tiles_1d) * ST;
+    const float* __restrict__ x = X + (size_t)b * P * P;
+    const float* __restrict__ y = Y + (size_t)b * P * P;
+    for (int e = threadIdx.x; e < (ST + 4) * (ST + 4); e += 256) {
+        const int r = e / (ST + 4), c = e - r * (ST + 4);
+        const int i = ti - 2 + r, j = tj - 2 + c;
+        const bool in = i >= 0 && i < P && j >= 0 && j < P;
+        xs[r][c] = in ? x[i * P + j] : 0.f;
+        ys[r][c] = in ? y[i * P + j] : 0.f;
+    }
+    __syncthreads();
+    const float k = -0.5f * scale * dLoss[0];
+    for (int e = threadIdx.x; e < (ST + 2) * (ST + 2); e += 256) {
+        const int r = e / (ST + 2), c = e - r * (ST + 2);
+        const int wi = ti - 2 + r, wj = tj - 2 + c;             // top-left pixel of window (r, c)
+        float a = 0.f, bt = 0.f, gm = 0.f;
+        if (wi >= 0 && wi <= P - 3 && wj >= 0 && wj <= P - 3) {
+            float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const float p = xs[r + u][c + v], q = ys[r + u][c + v];
+                    sx += p; sy += q; sxx += p * p; syy += q * q; sxy += p * q;
+                }
+            const float inv9 = 1.0f / 9.0f;
+            const float mux = sx * inv9, muy = sy * inv9;
+            const float sgx = sxx * inv9 - mux * mux, sgy = syy * inv9 - muy * muy, sgxy = sxy * inv9 - mux * muy;
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float A1 = 2.f * mux * muy + C1, A2 = 2.f * sgxy + C2;
+            const float B1 = mux * mux + muy * muy + C1, B2 = sgx + sgy + C2;
+            const float ssim = (A1 * A2) / (B1 * B2);
+            const float val = (1.f - ssim) * 0.5f;
+            if (val >= 0.f && val <= 1.f) {                       // clip_by_value passes the gradient inside [0, 1]
+                const float k9 = k * (2.0f / 9.0f);
+                gm = k9 * A1 / (B1 * B2);
+                bt = -k9 * ssim / B2;
+                a = k9 * (muy * (A2 - A1) / (B1 * B2) - ssim * mux * (1.0f / B1 - 1.0f / B2));
+            }
+        }
+        ca[r][c] = a; cb[r][c] = bt; cg[r][c] = gm;
+    }
+    __syncthreads();
+    const int li = threadIdx.x / ST, lj = threadIdx.x - li * ST;
+    const int i = ti + li, j = tj + lj;
+    if (i < P && j < P) {
+        float sa = 0.f, sb = 0.f, sg = 0.f;                        // windows with top-left (i-2..i, j-2..j) = coefficient rows li..li+2
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { sa += ca[li + u][lj + v]; sb += cb[li + u][lj + v]; sg += cg[li + u][lj + v]; }
+        dX[(size_t)b * P * P + i * P + j] = sa + sb * xs[li + 2][lj + 2] + sg * ys[li + 2][lj + 2];
     }
 }
 
@@ -115,6 +227,29 @@ using namespace uh;
 extern "C" size_t uh_patch_losses_workspace_bytes(int B, int P) {
     if (B <= 0 || P <= 0) return 0;
     return (size_t)B * ((P * P + 255) / 256) * NLS * sizeof(float);
+}
+
+extern "C" int uh_patch_loss_backward(int kind, const float* pred, const float* target, const float* stats16,
+                                      const float* dLoss, float* dPred, int B, int P, uh_stream_t stream) {
+    if (!pred || !target || !stats16 || !dLoss || !dPred) return UH_E_NULL;
+    if (B <= 0 || P < 3) return UH_E_SHAPE;
+    if (kind < UH_LOSS_REC || kind > UH_LOSS_NCC) return UH_E_SHAPE;
+    if ((uint64_t)B * P * P >= (1ull << 31)) return UH_E_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * P * P;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    switch (kind) {
+        case UH_LOSS_REC: launch_timed(UH_K_LOSS_BWD, patch_loss_backward_kernel<UH_LOSS_REC>, dim3(grid), dim3(256), s, pred, target, stats16, dLoss, dPred, n); break;
+        case UH_LOSS_L1: launch_timed(UH_K_LOSS_BWD, patch_loss_backward_kernel<UH_LOSS_L1>, dim3(grid), dim3(256), s, pred, target, stats16, dLoss, dPred, n); break;
+        case UH_LOSS_L1_SMOOTH: launch_timed(UH_K_LOSS_BWD, patch_loss_backward_kernel<UH_LOSS_L1_SMOOTH>, dim3(grid), dim3(256), s, pred, target, stats16, dLoss, dPred, n); break;
+        case UH_LOSS_NCC: launch_timed(UH_K_LOSS_BWD, patch_loss_backward_kernel<UH_LOSS_NCC>, dim3(grid), dim3(256), s, pred, target, stats16, dLoss, dPred, n); break;
+        default: {
+            const int t1 = (P + ST - 1) / ST;
+            launch_timed(UH_K_LOSS_BWD, patch_ssim_backward_kernel, dim3((unsigned)B * t1 * t1), dim3(256), s, pred, target, dLoss,
+                         dPred, P, t1, (float)(1.0 / ((double)B * (P - 2) * (P - 2))));
+        }
+    }
+    return (int)hipGetLastError();
 }
 
 extern "C" int uh_patch_losses_forward(const float* pred, const float* target, const float* h4p, const float* gt,

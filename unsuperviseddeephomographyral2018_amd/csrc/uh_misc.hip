@@ -181,7 +181,7 @@ extern "C" const char* uh_kernel_name(int k) {
                                             "warp_backward_finish", "gray_patch_forward", "gray_patch_backward",
                                             "l1_forward", "l1_backward", "warp_patch_l1_fused", "warp_patch_l1_finish",
                                             "patch_losses", "patch_losses_finish", "prepare_inputs",
-                                            "bias_relu_forward", "bias_relu_backward"};
+                                            "bias_relu_forward", "bias_relu_backward", "patch_loss_backward"};
     return (k >= 0 && k < UH_K_COUNT) ? names[k] : "?";
 }
 

@@ -45,9 +45,9 @@ extern "C" int uh_tail_create(uh_tail_plan** out, int B, int H, int W, int C, in
     p->off_dtheta = o;  o = align256(o + (size_t)B * 9 * sizeof(float));
     p->off_one = o;     o = align256(o + sizeof(float));
     p->off_warped = o;  o = align256(o + (fused ? 0 : frame));
-    p->off_dwarped = o; o = align256(o + (fused ? 0 : frame));
+    p->off_dwarped = o;                      // (no dWarped frame any more: the backward takes dPred directly)
     p->off_dpred = o;   o = align256(o + (fused ? 0 : patch));
-    p->off_ws_warp = o; o = align256(o + (fused ? 0 : uh_warp_backward_workspace_bytes(B, H, W, C, H, W)));
+    p->off_ws_warp = o; o = align256(o + (fused ? 0 : uh_warp_patch_backward_workspace_bytes(B, H, W, C)));
     p->off_ws_l1 = o;   o = align256(o + (fused ? 0 : uh_l1_loss_workspace_bytes((size_t)B * P * P)));
     p->off_ws_patch = o; o = align256(o + (fused ? uh_warp_patch_l1_workspace_bytes(B, P * P) : 0));
     p->total = o;
@@ -88,7 +88,6 @@ static int enqueue_chain(const uh_tail_plan* p, const float* pts1, const float* 
                                          uh_warp_patch_l1_workspace_bytes(B, PP), B, H, W, C, PP, s))) return e;
     } else {
         float* warped = (float*)(ws + p->off_warped);
-        float* dwarped = (float*)(ws + p->off_dwarped);
         float* dpred = (float*)(ws + p->off_dpred);
         float* one = (float*)(ws + p->off_one);
         const size_t n = (size_t)B * PP;
@@ -99,9 +98,9 @@ static int enqueue_chain(const uh_tail_plan* p, const float* pts1, const float* 
             hipError_t he = hipMemsetD32Async((hipDeviceptr_t)one, 0x3f800000, 1, s);      // dLoss = 1.0f
             if (he != hipSuccess) return (int)he;
             if ((e = uh_l1_loss_backward(pred, I2, one, dpred, n, s))) return e;
-            if ((e = uh_gray_patch_backward(dpred, idx, dwarped, B, H, W, C, PP, s))) return e;
-            if ((e = uh_warp_backward(U, theta, dwarped, dtheta, nullptr, ws + p->off_ws_warp,
-                                      uh_warp_backward_workspace_bytes(B, H, W, C, H, W), B, H, W, C, H, W, s))) return e;
+            // tf.gather's scatter + the dense warp backward, without the 79 %-zero frame in between
+            if ((e = uh_warp_patch_backward(U, theta, dpred, idx, dtheta, ws + p->off_ws_warp,
+                                            uh_warp_patch_backward_workspace_bytes(B, H, W, C), B, H, W, C, PP, s))) return e;
         }
     }
     if (dh4p) {

@@ -17,7 +17,9 @@
 //          the per-pixel weights are formed while the DMA is in flight;
 //       B  interior, rectangle too large (minifying regions): same cheap arithmetic, taps gathered from global
 //          memory with two offsets per pixel (the x+1 taps ride on the instruction's immediate offset);
-//       C  some tap is clipped (27-29 % of the tiles at the benchmark laws): the round-1 gather with clip_coord().
+//       C  some tap is clipped (27-42 % of the tiles at the benchmark laws): floor/clip per sample (clip_pair), then
+//          C1 the exact rectangle of the CLIPPED taps through LDS like A (four tap offsets per pixel), or
+//          C2 the direct gather when that rectangle does not fit (far field of a strong perspective).
 //     All three produce identical bits (tests/test_gpu_parity.py compares them with the f32 oracle and with the
 //     literal kernel below at full size).
 //   * Every wave owns a TW x (WY*STEPS) output tile (default 16 x 16: a square footprint keeps the taps of
@@ -77,7 +79,8 @@ constexpr int BT_F = UH_WARP_FWD_BATCH;
 constexpr int TPB_F = UH_WARP_FWD_TPB;
 static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the steps");
 #ifndef UH_WARP_FWD_MINW
-#define UH_WARP_FWD_MINW 1        // __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow
+#define UH_WARP_FWD_MINW 6        // __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow
+                                  // (6 x 4 waves x 6 KiB LDS slices = 144 KiB of the CU's 160 KiB; 80 VGPRs, no spill)
 #endif
 #ifndef UH_WARP_BWD_MINW
 #define UH_WARP_BWD_MINW 1
@@ -131,6 +134,25 @@ __device__ __forceinline__ Extent wave_extent(const float (&fx)[N], const float 
                  && g.Wm1 >= 1.0f && g.Hm1 >= 1.0f;
     e.bx0 = (int)__int_as_float(mnx); e.by0 = (int)__int_as_float(mny);
     e.rw = (int)__int_as_float(mxx) - e.bx0 + 2; e.rh = (int)__int_as_float(mxy) - e.by0 + 2;
+    return e;
+}
+
+// The same for a wave with clipped taps: exact extent of the CLIPPED corners (non-negative integers held in f32).
+template <int N>
+__device__ __forceinline__ Extent wave_extent_clipped(const float (&x0f)[N], const float (&x1f)[N], const float (&y0f)[N],
+                                                      const float (&y1f)[N]) {
+    int mnx = __float_as_int(x0f[0]), mxx = __float_as_int(x1f[0]), mny = __float_as_int(y0f[0]), mxy = __float_as_int(y1f[0]);
+#pragma unroll
+    for (int k = 1; k < N; ++k) {
+        mnx = min(mnx, __float_as_int(x0f[k])); mxx = max(mxx, __float_as_int(x1f[k]));
+        mny = min(mny, __float_as_int(y0f[k])); mxy = max(mxy, __float_as_int(y1f[k]));
+    }
+    mnx = wave_min_nonneg(mnx); mxx = wave_max_nonneg(mxx);
+    mny = wave_min_nonneg(mny); mxy = wave_max_nonneg(mxy);
+    Extent e;
+    e.interior = true;                       // (meaning here: the rectangle below holds every tap of the wave)
+    e.bx0 = (int)__int_as_float(mnx); e.by0 = (int)__int_as_float(mny);
+    e.rw = (int)__int_as_float(mxx) - e.bx0 + 1; e.rh = (int)__int_as_float(mxy) - e.by0 + 1;
     return e;
 }
 
@@ -321,21 +343,52 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
                 if (BT_F < STEPS) __builtin_amdgcn_sched_barrier(0);
             }
         }
-    } else {                                                            // ---- path C: clipped gather
+    } else {                                                            // ---- some tap is clipped
+        float x0f[STEPS], x1f[STEPS], y0f[STEPS], y1f[STEPS];
 #pragma unroll
-        for (int k0 = 0; k0 < STEPS; k0 += BT_F) {
-            Pix<C> Ia[BT_F], Ib[BT_F], Ic[BT_F], Id[BT_F];
-            Coord c[BT_F];
+        for (int k = 0; k < STEPS; ++k) {                               // fx / fy are dead from here on
+            clip_pair(p[k].x, g.Wm1, x0f[k], x1f[k]);                                           // (:101-109)
+            clip_pair(p[k].y, g.Hm1, y0f[k], y1f[k]);
+        }
+        Stage st;
+        st.fits = false;
+        Extent ec;
+        if constexpr (STAGE_FWD) { ec = wave_extent_clipped<STEPS>(x0f, x1f, y0f, y1f); st = plan_stage<C, LDSW>(ec); }
+#ifdef UH_WARP_NO_C1               // developer A/B switch: clipped waves always gather
+        st.fits = false;
+#endif
+        if (STAGE_FWD && st.fits) {                                     // ---- path C1: clipped rectangle through LDS
+            stage_dma<C, LDSW>(rin, lds, lane, ec, st, g.rowBi);
+            stage_wait();
 #pragma unroll
-            for (int j = 0; j < BT_F; ++j) {
-                c[j] = clip_coord(p[k0 + j], g);
-                const TapOff o = global_offsets<SMALL>(c[j], g);
-                Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
-                Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
+            for (int k = 0; k < STEPS; ++k) {
+                Coord c;
+                c.x0f = x0f[k]; c.x1f = x1f[k]; c.y0f = y0f[k]; c.y1f = y1f[k];
+                const TapOff o = staged_offsets(c, st.pitch, g.pixB, st.nbase);
+                const Pix<C> Ia = lds_load<C>(lds, o.oa), Ib = lds_load<C>(lds, o.ob);
+                const Pix<C> Ic = lds_load<C>(lds, o.oc), Id = lds_load<C>(lds, o.od);
+                emit(k, x1f[k] - p[k].x, p[k].x - x0f[k], y1f[k] - p[k].y, p[k].y - y0f[k], Ia, Ib, Ic, Id);   // (:130-137)
             }
+        } else {                                                        // ---- path C2: clipped gather (far field)
 #pragma unroll
-            for (int j = 0; j < BT_F; ++j) emit(k0 + j, c[j].ax1, c[j].ax0, c[j].ay1, c[j].ay0, Ia[j], Ib[j], Ic[j], Id[j]);
-            if (BT_F < STEPS) __builtin_amdgcn_sched_barrier(0);
+            for (int k0 = 0; k0 < STEPS; k0 += BT_F) {
+                Pix<C> Ia[BT_F], Ib[BT_F], Ic[BT_F], Id[BT_F];
+#pragma unroll
+                for (int j = 0; j < BT_F; ++j) {
+                    const int k = k0 + j;
+                    Coord c;
+                    c.x0f = x0f[k]; c.x1f = x1f[k]; c.y0f = y0f[k]; c.y1f = y1f[k];
+                    const TapOff o = global_offsets<SMALL>(c, g);
+                    Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
+                    Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < BT_F; ++j) {
+                    const int k = k0 + j;
+                    emit(k, x1f[k] - p[k].x, p[k].x - x0f[k], y1f[k] - p[k].y, p[k].y - y0f[k], Ia[j], Ib[j], Ic[j], Id[j]);
+                }
+                if (BT_F < STEPS) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     if (TPB_F > 1) {                    // the next tile's DMA must not overtake this tile's LDS reads
@@ -528,25 +581,54 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                     scatter(k, o, 1.0f - ax0[k], ax0[k], 1.0f - ay0[k], ay0[k], true);
                 }
             }
-        } else {                                                        // ---- path C: clipped gather
+        } else {                                                        // ---- some tap is clipped
+            float x0f[STEPS_B], x1f[STEPS_B], y0f[STEPS_B], y1f[STEPS_B];
 #pragma unroll
-            for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
-                Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];                 // 4*BT_B gathers in flight
-                Coord c[BT_B];
+            for (int k = 0; k < STEPS_B; ++k) {
+                clip_pair(p[k].x, g.Wm1, x0f[k], x1f[k]);
+                clip_pair(p[k].y, g.Hm1, y0f[k], y1f[k]);
+            }
+            Stage st;
+            st.fits = false;
+            Extent ec;
+            if constexpr (STAGE_BWD) { ec = wave_extent_clipped<STEPS_B>(x0f, x1f, y0f, y1f); st = plan_stage<C, LDSW>(ec); }
+#ifdef UH_WARP_NO_C1
+            st.fits = false;
+#endif
+            auto corners = [&](int k) { Coord c; c.x0f = x0f[k]; c.x1f = x1f[k]; c.y0f = y0f[k]; c.y1f = y1f[k]; return c; };
+            if (STAGE_BWD && st.fits) {                                 // ---- path C1: clipped rectangle through LDS
+                stage_dma<C, LDSW>(rin, lds, lane, ec, st, g.rowBi);
+                stage_wait();
 #pragma unroll
-                for (int j = 0; j < BT_B; ++j) {
-                    c[j] = clip_coord(p[k0 + j], g);
-                    const TapOff o = global_offsets<SMALL>(c[j], g);
-                    Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
-                    Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
+                for (int k = 0; k < STEPS_B; ++k) {
+                    const TapOff o = staged_offsets(corners(k), st.pitch, g.pixB, st.nbase);
+                    const Pix<C> Ia = lds_load<C>(lds, o.oa), Ib = lds_load<C>(lds, o.ob);
+                    const Pix<C> Ic = lds_load<C>(lds, o.oc), Id = lds_load<C>(lds, o.od);
+                    accumulate(k, x1f[k] - p[k].x, y1f[k] - p[k].y, x1f[k] - x0f[k], y1f[k] - y0f[k], Ia, Ib, Ic, Id);
                 }
+            } else {                                                    // ---- path C2: clipped gather (far field)
 #pragma unroll
-                for (int j = 0; j < BT_B; ++j) {
-                    accumulate(k0 + j, c[j].ax1, c[j].ay1, c[j].x1f - c[j].x0f, c[j].y1f - c[j].y0f, Ia[j], Ib[j], Ic[j], Id[j]);
-                    if (WANT_DU) scatter(k0 + j, global_offsets<SMALL>(c[j], g), c[j].ax1, c[j].ax0, c[j].ay1, c[j].ay0,
-                                         c[j].x1f != c[j].x0f && c[j].y1f != c[j].y0f);
+                for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
+                    Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];             // 4*BT_B gathers in flight
+#pragma unroll
+                    for (int j = 0; j < BT_B; ++j) {
+                        const TapOff o = global_offsets<SMALL>(corners(k0 + j), g);
+                        Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
+                        Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < BT_B; ++j) {
+                        const int k = k0 + j;
+                        accumulate(k, x1f[k] - p[k].x, y1f[k] - p[k].y, x1f[k] - x0f[k], y1f[k] - y0f[k], Ia[j], Ib[j], Ic[j], Id[j]);
+                    }
+                    if (BT_B < STEPS_B) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (BT_B < STEPS_B) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (WANT_DU) {
+#pragma unroll
+                for (int k = 0; k < STEPS_B; ++k)
+                    scatter(k, global_offsets<SMALL>(corners(k), g), x1f[k] - p[k].x, p[k].x - x0f[k], y1f[k] - p[k].y,
+                            p[k].y - y0f[k], x1f[k] != x0f[k] && y1f[k] != y0f[k]);
             }
         }
     }

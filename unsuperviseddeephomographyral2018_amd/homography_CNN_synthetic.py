@@ -80,6 +80,11 @@ def build_parser():
     p.add_argument('--graph_tail', type=str2bool, default='False',
                    help='l1_loss only: DLT -> warp -> loss and their backward as one library call / one hipGraph launch')
     p.add_argument('--fresh_data_every', type=int, default=1, help='draw a new synthetic batch every N steps')
+    p.add_argument('--texture', type=str, default='smooth', choices=['smooth', 'multiscale', 'white'],
+                   help='in-HBM synthetic image texture (synthetic.py); ignored with --data_path')
+    p.add_argument('--data_pool', type=int, default=0,
+                   help='> 0: pre-generate this many synthetic batches in HBM (118 MB each at 64 x 240x320: 288 GB holds '
+                        'thousands) and cycle through them in a fresh random order per pass, instead of generating per step')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--log_every', type=int, default=100)
     p.add_argument('--save_every', type=int, default=1000)
@@ -259,24 +264,42 @@ def train(args):
         loader = uh_data.Dataloader(prm, shuffle=True, device=device, seed=args.seed * 1000 + rank)
 
         disk = loader.stream()                 # endless, never drops a pair, raises on an empty list
+    pool, order = [], []
+    if disk is None and args.data_pool > 0:
+        pool = [synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
+                                     seed=args.seed + i * world + rank, device=device, kind=args.texture)
+                for i in range(args.data_pool)]
+        pool_gen = torch.Generator().manual_seed(args.seed * 7919 + rank)
+    window = torch.zeros(len(names), device=device)
+    win_n = 0
     t0 = time.time()
     for step in range(start_step, start_step + args.num_total_steps):
         if disk is not None:
             batch = next(disk)
+        elif pool:
+            if not order:
+                order = torch.randperm(len(pool), generator=pool_gen).tolist()
+            batch = pool[order.pop()]
         elif batch is None or (step - start_step) % max(args.fresh_data_every, 1) == 0:
             # every rank draws its own shard (seeded by step and rank) == tf.split of a global batch
             batch = synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
-                                         seed=args.seed + step * world + rank, device=device)
+                                         seed=args.seed + step * world + rank, device=device, kind=args.texture)
         model = step_fn(batch)
         vals = uh_dist.all_reduce_mean_scalars([getattr(model, n) for n in names], world)
-        totals += torch.stack([v.detach() for v in vals])
+        cur = torch.stack([v.detach() for v in vals])
+        totals += cur
+        window += cur
+        win_n += 1
         if rank == 0 and step % args.log_every == 0:
             n = step - start_step + 1
-            avg = (totals / n).tolist()
+            avg = (totals / n).tolist()                      # running means since the start, as the reference prints (:345-352)
+            win = (window / win_n).tolist()                  # ... and the mean over the steps since the previous log line
             dt = time.time() - t0
             print('Train: step %d  ' % step + ', '.join('%s %.6f' % (k, v) for k, v in zip(names, avg))
-                  + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9)),
+                  + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
+                  + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)]),
                   flush=True)
+            window.zero_(); win_n = 0
         if rank == 0 and step and step % args.save_every == 0:
             os.makedirs(ckpt_dir, exist_ok=True)
             torch.save(step_fn.state_dict(), ckpt)
@@ -335,7 +358,7 @@ class TestHomography(object):
             for step in range(num_steps):
                 batch = next(disk) if disk is not None else synthetic.make_batch(
                     a.batch_size, a.img_h, a.img_w, a.patch_size, a.rho, seed=10_000_000 + a.seed + step,
-                    device=self.device)
+                    device=self.device, kind=getattr(a, 'texture', 'smooth'))
                 m = HomographyModel(self.params, *synthetic.model_args(batch), reuse_variables=True, net=self.net,
                                     solve_f64=a.solve_f64)
                 total_bounded += float(m.bounded_h_loss)

@@ -211,9 +211,14 @@ class HomographyModel(object):
                                                              self.patch_indices, P)
             return
         self._l1_fused = None
-        warped_images, _ = ops.transformer(self.I, self._theta, out_size, with_condition=False)
-        self.warped_images = warped_images
-        self.pred_I2 = ops.gray_patch_gather(warped_images, self.patch_indices, P)
+        if self.fused_patch:
+            # the other photometric losses need a global norm before their gradient exists: sample the patch only
+            # (no warped frame), let the loss kernels produce dPred, then the sparse warp backward
+            self.pred_I2 = ops.warp_patch(self.I, self._theta, self.I2_aug, self.patch_indices, P)
+            return
+        # the reference's path: the full warped frame is materialised (:257), then gray + gather (:263-269) -- as ONE
+        # autograd node whose backward is the sparse warp backward (no 79 %-zero gradient frame)
+        self.warped_images, self.pred_I2 = ops.warp_gather(self.I, self._theta, self.patch_indices, P)
 
     # ---- homography_model.py:136-166 ----------------------------------------------------------------
     def _L1_smooth_loss(self, x, y):
@@ -254,27 +259,20 @@ class HomographyModel(object):
                 self.bounded_h_loss = torch.mean(batch_h_loss * (1 - is_failure) + is_failure * h_loss_identity)
 
         pred = self.pred_I2
-        # Every loss that is NOT being trained on is a stop_gradient monitor (homography_model.py:286-352): one
-        # HIP launch yields all of them (csrc/uh_losses.hip).  The trained loss keeps a differentiable path:
-        # l1_loss through the HIP L1 kernels (or the fused patch kernel), the others through torch autograd.
-        mon = ops.patch_losses(pred, I2, self.pred_h4p, self.gt)
+        # ONE launch yields all six values (csrc/uh_losses.hip); the loss being trained on carries its gradient through
+        # uh_patch_loss_backward (HIP), every other one is a stop_gradient monitor (homography_model.py:286-352).
+        grad = torch.is_grad_enabled()
+        train = lt if (grad and lt != 'h_loss' and not (lt == 'l1_loss' and self._l1_fused is not None)) else None
+        mon = ops.patch_losses(pred, I2, self.pred_h4p, self.gt, train=train)
         self.h_loss, self.rec_loss, self.ssim_loss = mon[5], mon[0], mon[1]
         self.l1_loss, self.l1_smooth_loss, self.ncc_loss = mon[2], mon[3], mon[4]
-        if not torch.is_grad_enabled():
+        if not grad:
             return
         if lt == 'h_loss':
             self.h_loss = torch.sqrt(torch.mean((self.pred_h4p - self.gt) ** 2))
-        elif lt == 'rec_loss':
-            self.rec_loss = torch.sqrt(torch.mean((pred - I2) ** 2))
-        elif lt == 'ssim_loss':
-            self.ssim_loss = torch.mean(self._SSIM_loss(pred, I2))
-        elif lt == 'l1_loss':
-            # the photometric L1 of the hot path: HIP reduction kernel (or the fused patch kernel's output)
-            self.l1_loss = self._l1_fused if self._l1_fused is not None else ops.l1_loss(pred, I2)
-        elif lt == 'l1_smooth_loss':
-            self.l1_smooth_loss = self._L1_smooth_loss(pred, I2)
-        elif lt == 'ncc_loss':
-            self.ncc_loss = self._NCC_loss(I2, pred)
+        elif lt == 'l1_loss' and self._l1_fused is not None:
+            # fused patch kernel / tail graph: loss and d loss / d theta came out of the sampling pass itself
+            self.l1_loss = self._l1_fused
 
     @property
     def loss(self):

@@ -288,24 +288,61 @@ def l1_loss(pred, target):
     return _L1Loss.apply(pred, target)
 
 
-def patch_losses(pred, target, h4p=None, gt=None):
-    """All photometric losses of build_losses() in one launch, forward values only (homography_model.py:136-166,
-    286-352): returns a [6] tensor (rec, ssim, l1, l1_smooth, ncc, h_loss); h_loss = 0 unless h4p and gt are given."""
-    lib = _lib.load()
-    pred = _f32(pred.detach(), 'pred'); target = _f32(target.detach(), 'target')
+class _PatchLosses(torch.autograd.Function):
+    """(pred, target[, h4p, gt]) -> [6] (rec, ssim, l1, l1_smooth, ncc, h_loss) in one launch; element `kind` (the loss
+    being trained on) carries d/d pred through uh_patch_loss_backward, the others are stop_gradient monitors exactly as
+    in build_losses() (homography_model.py:286-352)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, h4p, gt, kind):
+        lib = _lib.load()
+        pred = _f32(pred, 'pred'); target = _f32(target, 'target')
+        B, P = pred.shape[0], pred.shape[1]
+        out = torch.empty((16,), dtype=torch.float32, device=pred.device)
+        nbytes = lib.uh_patch_losses_workspace_bytes(B, P)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=pred.device)
+        _lib.check(lib.uh_patch_losses_forward(_ptr(pred), _ptr(target), _ptr(h4p), _ptr(gt), _ptr(out), _ptr(ws), nbytes,
+                                               B, P, _stream()), 'uh_patch_losses_forward')
+        ctx.kind = kind
+        ctx.dims = (B, P)
+        if kind >= 0:
+            ctx.save_for_backward(pred, target, out)
+        return out[:6]
+
+    @staticmethod
+    def backward(ctx, dOut):
+        if ctx.kind < 0 or not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        lib = _lib.load()
+        pred, target, stats = ctx.saved_tensors
+        B, P = ctx.dims
+        g = _f32(dOut[ctx.kind:ctx.kind + 1], 'dLoss')
+        dPred = torch.empty_like(pred)
+        _lib.check(lib.uh_patch_loss_backward(ctx.kind, _ptr(pred), _ptr(target), _ptr(stats), _ptr(g), _ptr(dPred), B, P,
+                                              _stream()), 'uh_patch_loss_backward')
+        return dPred, None, None, None, None
+
+
+def patch_losses(pred, target, h4p=None, gt=None, train=None):
+    """All photometric losses of build_losses() in one launch (homography_model.py:136-166, 286-352): returns a [6]
+    tensor (rec, ssim, l1, l1_smooth, ncc, h_loss); h_loss = 0 unless h4p and gt are given.  `train` names the loss
+    that is being trained on ('rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss'): that element is
+    differentiable w.r.t. pred (HIP gradient kernel); every other element is a stop_gradient monitor."""
     if pred.dim() != 4 or pred.shape[3] != 1 or pred.shape[1] != pred.shape[2] or target.shape != pred.shape:
         raise _lib.UHError('patch_losses expects pred and target of shape [B,P,P,1]')
-    B, P = pred.shape[0], pred.shape[1]
+    B = pred.shape[0]
     if h4p is not None:
         h4p = _f32(h4p.detach(), 'h4p').reshape(-1); gt = _f32(gt.detach(), 'gt').reshape(-1)
         if h4p.numel() != B * 8 or gt.numel() != B * 8:
             raise _lib.UHError('h4p and gt must be [B,8]')
-    out = torch.empty((6,), dtype=torch.float32, device=pred.device)
-    nbytes = lib.uh_patch_losses_workspace_bytes(B, P)
-    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=pred.device)
-    _lib.check(lib.uh_patch_losses_forward(_ptr(pred), _ptr(target), _ptr(h4p), _ptr(gt), _ptr(out), _ptr(ws), nbytes,
-                                           B, P, _stream()), 'uh_patch_losses_forward')
-    return out
+    kind = -1
+    if train is not None:
+        if train not in _lib.LOSS_KINDS:
+            raise _lib.UHError('patch_losses: no gradient kernel for %r' % (train,))
+        kind = _lib.LOSS_KINDS[train]
+    if kind < 0:
+        pred = pred.detach()
+    return _PatchLosses.apply(pred, target.detach(), h4p, gt, kind)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -340,6 +377,53 @@ class _WarpPatchL1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dLoss, dPred=None):
         return None, (ctx.dTheta * dLoss).reshape(-1, 9), None, None, None
+
+
+class _WarpPatch(torch.autograd.Function):
+    """Fused patch path for the losses that need a global norm before their gradient exists (rec, ssim, smooth-l1, ncc):
+    pred_I2 = gather(gray(warp(U, theta)), patch_indices) sampled on the patch only (the warped frame never exists);
+    d pred_I2 / d theta by uh_warp_patch_backward once the loss kernel has produced dPred."""
+
+    @staticmethod
+    def forward(ctx, U, theta, I2, patch_idx, patch_size):
+        lib = _lib.load()
+        U = _f32(U, 'U'); I2 = _f32(I2, 'I2')
+        B, H, W, Cc = U.shape
+        theta9 = _f32(theta, 'theta').reshape(-1, 9)
+        if patch_idx.dtype != torch.int32 or not patch_idx.is_cuda:
+            raise _lib.UHError('patch_indices must be an int32 tensor on the HIP device')
+        idx = patch_idx.contiguous().reshape(B, -1)
+        PP = idx.shape[1]
+        pred = torch.empty((B, PP), dtype=torch.float32, device=U.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=U.device)
+        nbytes = lib.uh_warp_patch_l1_workspace_bytes(B, PP)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_warp_patch_l1_fwdbwd(_ptr(U), _ptr(theta9), _ptr(I2), _ptr(idx), _ptr(pred), _ptr(loss), None,
+                                               _ptr(ws), nbytes, B, H, W, Cc, PP, _stream()), 'uh_warp_patch_l1_fwdbwd')
+        ctx.save_for_backward(U, theta9, idx)
+        ctx.dims = (B, H, W, Cc, PP)
+        ctx.theta_shape = theta.shape
+        return pred.reshape(B, patch_size, patch_size, 1)
+
+    @staticmethod
+    def backward(ctx, dPred):
+        lib = _lib.load()
+        U, theta9, idx = ctx.saved_tensors
+        B, H, W, Cc, PP = ctx.dims
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None
+        dPred = _f32(dPred, 'dPred')
+        dT = torch.empty((B, 9), dtype=torch.float32, device=U.device)
+        nbytes = lib.uh_warp_patch_backward_workspace_bytes(B, H, W, Cc)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_warp_patch_backward(_ptr(U), _ptr(theta9), _ptr(dPred), _ptr(idx), _ptr(dT), _ptr(ws), nbytes,
+                                              B, H, W, Cc, PP, _stream()), 'uh_warp_patch_backward')
+        return None, dT.reshape(ctx.theta_shape), None, None, None
+
+
+def warp_patch(U, theta, I2, patch_indices, patch_size):
+    """-> pred_I2 [B,P,P,1] sampled on the patch only; differentiable w.r.t. theta (sparse warp backward)."""
+    return _WarpPatch.apply(U, theta, I2, patch_indices, patch_size)
 
 
 def warp_patch_l1(U, theta, I2, patch_indices, patch_size):

@@ -32,6 +32,20 @@ def smooth_images(B, H, W, generator, device):
     return ((img - mean) / std).permute(0, 2, 3, 1).contiguous()           # NHWC
 
 
+def multiscale_images(B, H, W, generator, device, octaves=(64, 32, 16, 8, 4)):
+    """Sum of bilinearly upsampled uniform noise at 1/64 ... 1/4 resolution with amplitude ~ cell size^0.5: a 1/f-like
+    spectrum, closer to the photographs the reference trains on (MS-COCO) than the single-octave `smooth` texture.
+    The coarse octaves give the photometric loss a gradient that points the right way from tens of pixels out; with
+    one 8-px octave alone the loss surface at a 26 px mean displacement is a field of unrelated local minima."""
+    img = torch.zeros(B, 3, H, W, device=device)
+    for s in octaves:
+        lo = torch.rand(B, 3, H // s + 2, W // s + 2, generator=generator, device=device) - 0.5
+        w = float(s) ** 0.5
+        img = img + w * torch.nn.functional.interpolate(lo, size=(H, W), mode='bilinear', align_corners=True)
+    img = img / img.std()                                              # unit variance, like the "(x - mean)/std" frames
+    return img.permute(0, 2, 3, 1).contiguous()                       # NHWC
+
+
 def make_batch(B, img_h=240, img_w=320, patch_size=128, rho=45, seed=0, device='cuda', kind='smooth'):
     """-> dict(I1, I2, I1_aug, I2_aug, I_aug, I_prime_aug, pts1, gt, patch_indices) on `device`."""
     dev = torch.device(device)
@@ -41,6 +55,8 @@ def make_batch(B, img_h=240, img_w=320, patch_size=128, rho=45, seed=0, device='
         raise ValueError('patch + 2*rho does not fit the frame')
     if kind == 'smooth':
         I = smooth_images(B, H, W, g, dev)
+    elif kind == 'multiscale':
+        I = multiscale_images(B, H, W, g, dev)
     else:
         I = torch.randn(B, H, W, 3, generator=g, device=dev)
     x0 = torch.randint(rho, W - rho - P + 1, (B,), generator=g, device=dev)
