@@ -13,6 +13,8 @@ BASELINE.json configs[1]: batch 64, 240x320 I/I', 128x128 patch, RHO=45, photome
 --loss_type l1_loss).  N > 1: weak scaling, 64 pairs per GPU (configs[2]: 8 x 64 = 512).
 
 Rank 0 prints ONE JSON line; extra objects:
+  config4_point / north_star_point -- the warp kernels alone (dense dOut) at BASELINE configs[3] (480x640, rho 64,
+                  batch 128: HBM-resident) and at north_star's batch-128 240x320 point, with the path mix of the tiles.
   roofline     -- dominant hot-path kernel (full-frame warp, forward or backward, whichever took more
                   time): algorithmic bytes per launch / average launch duration measured with HIP
                   events on the launch stream (uh_profile_*) inside the timed region, vs 8 TB/s HBM.
@@ -50,6 +52,11 @@ def parse():
     ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object); 1: time the warp kernels; 2: time every library kernel')
     ap.add_argument('--cpu_baseline', type=int, default=1)
     ap.add_argument('--north_star', type=int, default=1, help='0: skip the extra warp-only measurement at batch 128')
+    ap.add_argument('--config4', type=int, default=1, help='0: skip the extra warp-only measurement at BASELINE configs[3] (480x640, rho 64, batch 128)')
+    ap.add_argument('--mid_training_theta', type=int, default=1,
+                    help='1: add gt + N(0, 2 px) to the regressor output inside the timed steps, so that theta follows SURVEY '
+                         '8(d)\'s mid-training law (perspective, clipped and far-field tiles) instead of the near-identity a '
+                         '25-step-old regressor predicts; 0: the raw regressor')
     ap.add_argument('--cpu_sample_pairs', type=int, default=64, help='CPU leg: batch size (default = the GPU batch)')
     ap.add_argument('--cpu_sample_steps', type=int, default=4, help='CPU leg: timed steps after one warm-up step')
     ap.add_argument('--cpu_threads', type=int, default=32, help='host threads for the CPU leg (capped at nproc)')
@@ -93,20 +100,60 @@ def cpu_baseline(args):
                                                                                  os.cpu_count() or 1, dt)}
 
 
-def north_star_point(device, args, B=128, iters=30):
-    """Warp forward + backward alone at north_star's point (batch 128, 240x320, theta from gt + 2 px noise):
-    HIP-event kernel times via uh_profile_*, algorithmic bytes 4*B*H*W*C*4, fraction of the 8 TB/s roofline."""
+def tile_paths(theta, H, W, lds_bytes=6144, tile=16):
+    """Which path each 16x16 wave tile of uh_warp_forward takes under `theta` [B,9] (csrc/uh_warp.hip): A = interior,
+    tap rectangle fits the wave's LDS slice (LDS-DMA staged); B = interior, rectangle too large (gather); C1 / C2 = some
+    tap clipped, rectangle of the clipped taps fits / does not fit.  Re-derived here with torch ops in f32 (statistics
+    only: a tile on a rounding edge may be classified differently from the kernel)."""
+    B = theta.shape[0]
+    th = theta.reshape(B, 3, 3).float()
+    dev = theta.device
+    gx = -1.0 + (2.0 / (W - 1)) * torch.arange(W, device=dev, dtype=torch.float32)
+    gy = -1.0 + (2.0 / (H - 1)) * torch.arange(H, device=dev, dtype=torch.float32)
+    GX, GY = gx[None, None, :], gy[None, :, None]
+    row = lambda r: th[:, r, 0, None, None] * GX + th[:, r, 1, None, None] * GY + th[:, r, 2, None, None]
+    t = row(2)
+    t = torch.where(t.abs() >= 1e-7, t, t + 1e-6)
+    x = (row(0) / t + 1.0) * W * 0.5
+    y = (row(1) / t + 1.0) * H * 0.5
+    fx, fy = torch.floor(x), torch.floor(y)
+    big = 2147483648.0
+    fx = torch.where((fx < big) & (fx >= -big), fx, torch.full_like(fx, -1.0)); fy = torch.where((fy < big) & (fy >= -big), fy, torch.full_like(fy, -1.0))
+    Ht, Wt = H // tile, W // tile
+    T = lambda a: a[:, :Ht * tile, :Wt * tile].reshape(B, Ht, tile, Wt, tile)
+    mn = lambda a: T(a).amin(dim=(2, 4)); mx = lambda a: T(a).amax(dim=(2, 4))
+    interior = (mn(fx) >= 0) & (mx(fx) + 1 <= W - 1) & (mn(fy) >= 0) & (mx(fy) + 1 <= H - 1)
+
+    def fits(x0, x1, y0, y1):
+        rw, rh = x1 - x0 + 1, y1 - y0 + 1
+        cpr = torch.ceil(rw * 12 / 16)
+        return (cpr <= 64) & (torch.ceil(cpr * rh / 64) * 1024 <= lds_bytes)
+    fitA = fits(mn(fx), mx(fx) + 1, mn(fy), mx(fy) + 1)
+    cx0, cx1 = fx.clamp(0, W - 1), (fx + 1).clamp(0, W - 1)
+    cy0, cy1 = fy.clamp(0, H - 1), (fy + 1).clamp(0, H - 1)
+    fitC = fits(mn(cx0), mx(cx1), mn(cy0), mx(cy1))
+    n = float(interior.numel())
+    return {'A_staged_interior': round(float((interior & fitA).sum()) / n, 4),
+            'B_gather_interior': round(float((interior & ~fitA).sum()) / n, 4),
+            'C1_staged_clipped': round(float((~interior & fitC).sum()) / n, 4),
+            'C2_gather_clipped': round(float((~interior & ~fitC).sum()) / n, 4)}
+
+
+def warp_point(device, B, H, W, P, rho, iters=20, seed=7):
+    """Warp forward + backward alone (dense dOut) under the mid-training law theta = DLT(gt + N(0, 2 px)): HIP-event
+    kernel durations via uh_profile_*, algorithmic bytes 4*B*H*W*C*4, fraction of the 8 TB/s roofline."""
     from unsuperviseddeephomographyral2018_amd import _lib, ops, synthetic
-    H, W = args.img_h, args.img_w
-    b = synthetic.make_batch(B, H, W, args.patch_size, args.rho, seed=7, device=device)
+    b = synthetic.make_batch(B, H, W, P, rho, seed=seed, device=device)
     g = torch.Generator(device=device).manual_seed(3)
     pred = b['gt'] + 2.0 * torch.randn(B, 8, generator=g, device=device)
     _, theta = ops.solve_dlt(b['pts1'], pred, img_w=W, img_h=H)
     dOut = torch.randn(B, H, W, 3, generator=g, device=device)
+    U = b['I_aug']
+    del b
 
     def once():
         t = theta.detach().clone().requires_grad_(True)
-        out, _ = ops.transformer(b['I_aug'], t, (H, W), with_condition=False)
+        out, _ = ops.transformer(U, t, (H, W), with_condition=False)
         out.backward(dOut)
 
     for _ in range(3):
@@ -121,12 +168,25 @@ def north_star_point(device, args, B=128, iters=30):
     us = {k: prof[k][0] / prof[k][1] * 1e3 for k in ('warp_forward', 'warp_backward', 'warp_backward_finish')}
     nbytes = 4 * B * H * W * 3 * 4
     t_total = (us['warp_forward'] + us['warp_backward'] + us['warp_backward_finish']) * 1e-6
-    return {'workload': 'warp fwd+bwd(dTheta), batch %d, %dx%d, C=3, theta = DLT(gt + N(0,2px))' % (B, H, W),
+    return {'workload': 'warp fwd+bwd(dTheta), batch %d, %dx%d, C=3, rho=%d, theta = DLT(gt + N(0,2px))' % (B, H, W, rho),
             'fwd_us': round(us['warp_forward'], 2), 'bwd_us': round(us['warp_backward'], 2),
             'bwd_finish_us': round(us['warp_backward_finish'], 2), 'algorithmic_MB': round(nbytes / 1e6, 1),
             'achieved_GBs': round(nbytes / t_total / 1e9, 1), 'frac_of_8TBs': round(nbytes / t_total / HBM_PEAK, 4),
             'fwd_frac': round(nbytes / 2 / (us['warp_forward'] * 1e-6) / HBM_PEAK, 4),
-            'bwd_frac': round(nbytes / 2 / (us['warp_backward'] * 1e-6) / HBM_PEAK, 4)}
+            'bwd_frac': round(nbytes / 2 / (us['warp_backward'] * 1e-6) / HBM_PEAK, 4),
+            'tile_paths': tile_paths(theta.detach(), H, W),
+            'timing': 'HIP start/stop events of each dispatch (uh_profile_*), %d launches' % iters}
+
+
+def north_star_point(device, args):
+    """north_star's point: batch 128, 240x320 (working set 354 MB: partly Infinity-Cache resident)."""
+    return warp_point(device, 128, args.img_h, args.img_w, args.patch_size, args.rho, iters=30)
+
+
+def config4_point(device, args):
+    """BASELINE.json configs[3]: full-frame 480x640 warp, rho = 64, batch 128 -- 1.9 GB working set, far beyond the
+    256 MB Infinity Cache: the HBM-resident roofline point."""
+    return warp_point(device, 128, 480, 640, args.patch_size, 64, iters=20)
 
 
 def main():
@@ -158,9 +218,13 @@ def main():
     # synthetic pairs, generated once, resident in HBM before the timed region; each rank its own shard
     batch = synthetic.make_batch(B, args.img_h, args.img_w, args.patch_size, args.rho, seed=100 + rank,
                                  device=device)
-    # NOTE: a freshly initialised regressor predicts small deltas, so theta in the timed steps is close to the
-    # identity; `north_star_point` below re-measures the warp kernels alone under the mid-training law
-    # (pred = gt + N(0, 2 px)) of SURVEY section 8(d), at the B=128 point north_star quotes.
+    # A freshly initialised regressor predicts small deltas, i.e. theta ~ identity: the easy case for the warp (every
+    # tile interior and staged).  --mid_training_theta 1 (default) adds gt + N(0, 2 px) to its output so that the timed
+    # steps run the warp under SURVEY section 8(d)'s mid-training law (clipped and far-field tiles included); the step
+    # (conv fwd/bwd, hot path fwd/bwd, Adam) is otherwise unchanged.  `in_step_theta` in the line says which law ran.
+    if args.mid_training_theta:
+        g = torch.Generator(device=device).manual_seed(4321 + rank)
+        step_fn.h4p_offset = batch['gt'] + 2.0 * torch.randn(B, 8, generator=g, device=device)
     for _ in range(args.warmup):
         model = step_fn(batch)
     torch.cuda.synchronize(device)
@@ -181,12 +245,26 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.profile_read()
     _lib.profile_enable(False)
+    from unsuperviseddeephomographyral2018_amd import ops as _ops
+    with torch.no_grad():
+        _, th_last = _ops.solve_dlt(batch['pts1'], model.pred_h4p.detach(), img_w=args.img_w, img_h=args.img_h)
+        in_step_theta = {'law': 'regressor + gt + N(0,2px)' if args.mid_training_theta else 'raw regressor (near identity)',
+                         'tile_paths': tile_paths(th_last, args.img_h, args.img_w)}
     loss_val = float(model.loss.detach())
     h_loss_val = float(model.h_loss.detach())              # mean corner error (RMSE px) of the last batch: the net is 35 steps old
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    exchange = None
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        av = step_fn.averager
+        # the exchange step on its own (collective, every rank takes part): per-bucket all-reduce time with nothing to hide
+        # under, next to the host time finish() spent blocked per step inside the timed region
+        exchange = {'buckets': av.time_buckets(iters=5), 'reduce_op': 'AVG' if av._avg_in_collective else 'SUM+div',
+                    'host_blocked_ms_per_step': round(av.exposed_wait_s / max(av.finishes, 1) * 1e3, 4),
+                    'note': 'bucket 0 = fc2+fc1 (issued first in backward, overlaps the conv backward), bucket 1 = conv; '
+                            'RCCL wait() only enqueues a stream dependency, so host_blocked is ~0 by construction: compare '
+                            'ms_per_step with the N=1 line to see what the exchange really costs'}
     dt = float(tt.item())
     if rank != 0:
         if world > 1:
@@ -219,14 +297,18 @@ def main():
                               'uh_profile_*), inside the timed region', 'kernels': kern}
     # HBM bytes per launch of the dominant kernel from the PMC passes over THIS command (tools/gpu_traffic.sh ->
     # profiles/traffic_r01.json; FETCH_SIZE x2 KiB + WRITE_SIZE KiB, the gfx950 correction calibrated on a device copy)
-    traffic_file = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
+    traffic_file = os.path.join(ROOT, 'profiles', 'traffic_r02.json')
+    if not os.path.exists(traffic_file):
+        traffic_file = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
     if dom is not None and os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             key = '%s_B%d_%dx%d' % (dom, B, args.img_h, args.img_w)
             if key in tr:
                 roofline['traffic'] = tr[key]['hbm_bytes_per_launch']
-                roofline['traffic_source'] = tr[key].get('source', 'profiles/traffic_r01.json')
+                roofline['traffic_source'] = tr[key].get('source', os.path.basename(traffic_file))
+                roofline['traffic_note'] = ('NOT measured in this run: read from the committed file %s (%s)'
+                                            % (os.path.relpath(traffic_file, ROOT), tr.get('_provenance', 'no provenance recorded')))
         except Exception:
             pass
     out = {
@@ -240,11 +322,20 @@ def main():
                        B, args.img_h, args.img_w, args.patch_size, args.patch_size, args.rho,
                        ' (fused patch kernel)' if args.fused_patch else ''),
                    'global_batch': global_batch, 'loss_type': args.loss_type, 'parallelism': 'dp%d' % world,
-                   'final_loss': round(loss_val, 6), 'mean_corner_error_px_after_%d_steps' % (args.steps + args.warmup): round(h_loss_val, 3)},
+                   'final_loss': round(loss_val, 6),
+                   ('corner_error_px_of_offset_prediction' if args.mid_training_theta else
+                    'mean_corner_error_px_after_%d_steps' % (args.steps + args.warmup)): round(h_loss_val, 3)},
         'roofline': roofline,
     }
+    out['config']['in_step_theta'] = in_step_theta
+    if world > 1:
+        out['config']['rccl_world_size'] = torch.distributed.get_world_size()
+        out['config']['dist_backend'] = torch.distributed.get_backend()
+        out['exchange'] = exchange
     if world == 1 and args.north_star:
         out['north_star_point'] = north_star_point(device, args)
+    if world == 1 and args.config4:
+        out['config4_point'] = config4_point(device, args)
     if world == 1 and args.cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

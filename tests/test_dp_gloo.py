@@ -28,19 +28,21 @@ class Tiny(nn.Module):
         return self.fc2(torch.relu(self.fc1(x.flatten(1))))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend='gloo'):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     from unsuperviseddeephomographyral2018_amd import dist as D
-    r, w, _ = D.init_from_env(backend='gloo')
+    r, w, local = D.init_from_env(backend=backend)
     assert (r, w) == (rank, world)
+    dev = torch.device('cuda', local) if backend == 'nccl' else torch.device('cpu')
     torch.manual_seed(0)
-    net = Tiny()
+    net = Tiny().to(dev)
     for p in net.parameters():
         torch.distributed.broadcast(p.data, src=0)
     g = torch.Generator().manual_seed(1)
-    X = torch.randn(8, 2, 8, 8, generator=g); Y = torch.randn(8, 8, generator=g)
+    X = torch.randn(8, 2, 8, 8, generator=g).to(dev); Y = torch.randn(8, 8, generator=g).to(dev)
     avg = D.GradAverager(net, world)
+    assert avg._avg_in_collective == (backend == 'nccl')        # RCCL averages inside the collective (ReduceOp.AVG)
     assert len(avg.buckets) == 2 and avg.buckets[0]['flat'].numel() == sum(
         p.numel() for n, p in net.named_parameters() if n.startswith('fc'))
     res = []
@@ -52,16 +54,32 @@ def _worker(rank, world, port, q):
         avg.finish()
         res.append([p.grad.clone() for p in net.parameters()])
     vals = D.all_reduce_mean_scalars([loss], world)
-    q.put((rank, [[t.numpy() for t in r_] for r_ in res], float(vals[0])))
+    if backend == 'nccl':
+        tb = avg.time_buckets(iters=2)
+        assert len(tb) == 2 and all(b['ms'] > 0 for b in tb)
+    q.put((rank, [[t.cpu().numpy() for t in r_] for r_ in res], float(vals[0])))
     torch.distributed.destroy_process_group()
 
 
 def test_grad_averager_world2_equals_full_batch_gradient():
+    _run_world2('gloo')
+
+
+@pytest.mark.gpu
+def test_grad_averager_world2_rccl():
+    """The same exchange step over RCCL (backend "nccl") on two real GPUs: rank-equal averaged gradients that equal the
+    one-process full-batch gradient.  Activates itself on any box with >= 2 devices (the driver's 8-GPU node)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 HIP devices (RCCL wants one device per rank)')
+    _run_world2('nccl')
+
+
+def _run_world2(backend):
     import numpy as np
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=120) for _ in range(world)]
@@ -79,7 +97,7 @@ def test_grad_averager_world2_equals_full_batch_gradient():
     for it in range(2):
         for a, b, r in zip(out[0][1][it], out[1][1][it], ref):
             np.testing.assert_allclose(a, b, rtol=0, atol=0)          # both ranks hold the same mean
-            np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(a, r, rtol=1e-5 if backend == 'gloo' else 1e-4, atol=1e-7 if backend == 'gloo' else 1e-6)
     assert abs(out[0][2] - out[1][2]) < 1e-7
 
 

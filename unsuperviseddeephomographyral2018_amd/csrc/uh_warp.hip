@@ -240,6 +240,18 @@ __device__ __forceinline__ void global_quad(__amdgpu_buffer_rsrc_t rin, unsigned
     Ib = buf_load<C>(rin, ob, 0); Id = buf_load<C>(rin, ob + C * 4, 0);
 }
 
+#ifdef UH_WARP_TRACE
+// Developer instrumentation (tools/trace_waves.py; never in the shipped library): lane 0 of every forward wave records
+// s_memtime at its phase boundaries and the path it took.  trace[w*8 + ..] = t0 entry, t1 decision made, t2 loads /
+// DMA issued, t3 data landed, t4 stores issued, [5] path (0 A, 1 B, 2 C1, 3 C2), [6] DMA instructions.
+__device__ unsigned long long* g_trace = nullptr;
+#define UH_TR(i) do { if (trp) trp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define UH_TRV(i, v) do { if (trp) trp[i] = (unsigned long long)(v); } while (0)
+#else
+#define UH_TR(i) do {} while (0)
+#define UH_TRV(i, v) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 template <int C, bool COND, bool SMALL>
 __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
@@ -263,6 +275,10 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
     const int col = (tx * NWAVE + wave) * TW + (lane & (TW - 1));
     const int row0 = ty * TH + (lane / TW);                              // this lane's first row
     if ((tx * NWAVE + wave) * TW >= ow) continue;                        // whole wave outside (wave-uniform)
+#ifdef UH_WARP_TRACE
+    unsigned long long* trp = (g_trace && lane == 0) ? g_trace + ((size_t)v * NWAVE + wave) * 8 : nullptr;
+#endif
+    UH_TR(0);
     const Theta th = load_theta(theta, b);
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(U + (size_t)b * H * W * C, (unsigned)(H * W * C * 4));
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out + (size_t)b * oh * ow * C, (unsigned)(oh * ow * C * 4));
@@ -281,6 +297,7 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
         fx[k] = floorf(p[k].x); fy[k] = floorf(p[k].y);                                         // (:101,103)
     }
     const Extent e = wave_extent<STEPS>(fx, fy, g);
+    UH_TR(1);
 
     // Store offsets: row*orow + col*pixB, advanced by WY rows per step.  A row >= oh gives an offset >= the
     // buffer's num_records (= oh*orow), which makes the buffer unit drop the store; lanes right of the image
@@ -315,14 +332,18 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
                 oa[k] = (unsigned)__builtin_fmaf(fy[k], st.pitch, __builtin_fmaf(fx[k], g.pixB, st.nbase));
             }
             const unsigned pitchi = (unsigned)(st.cpr * 16);
+            UH_TR(2); UH_TRV(5, 0); UH_TRV(6, st.nld);
             stage_wait();
+            UH_TR(3);
 #pragma unroll
             for (int k = 0; k < STEPS; ++k) {
                 Pix<C> Ia, Ib, Ic, Id;
                 lds_quad<C>(lds, oa[k], oa[k] + pitchi, Ia, Ib, Ic, Id);
                 emit(k, 1.0f - ax0[k], ax0[k], 1.0f - ay0[k], ay0[k], Ia, Ib, Ic, Id);
             }
+            UH_TR(4);
         } else {                                                        // ---- path B
+            UH_TR(2); UH_TRV(5, 1); UH_TRV(6, 0);
 #pragma unroll
             for (int k0 = 0; k0 < STEPS; k0 += BT_F) {
                 Pix<C> Ia[BT_F], Ib[BT_F], Ic[BT_F], Id[BT_F];                 // 4*BT_F gathers in flight
@@ -342,6 +363,7 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
                 }
                 if (BT_F < STEPS) __builtin_amdgcn_sched_barrier(0);
             }
+            UH_TR(3); UH_TR(4);
         }
     } else {                                                            // ---- some tap is clipped
         float x0f[STEPS], x1f[STEPS], y0f[STEPS], y1f[STEPS];
@@ -359,7 +381,9 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
 #endif
         if (STAGE_FWD && st.fits) {                                     // ---- path C1: clipped rectangle through LDS
             stage_dma<C, LDSW>(rin, lds, lane, ec, st, g.rowBi);
+            UH_TR(2); UH_TRV(5, 2); UH_TRV(6, st.nld);
             stage_wait();
+            UH_TR(3);
 #pragma unroll
             for (int k = 0; k < STEPS; ++k) {
                 Coord c;
@@ -369,7 +393,9 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
                 const Pix<C> Ic = lds_load<C>(lds, o.oc), Id = lds_load<C>(lds, o.od);
                 emit(k, x1f[k] - p[k].x, p[k].x - x0f[k], y1f[k] - p[k].y, p[k].y - y0f[k], Ia, Ib, Ic, Id);   // (:130-137)
             }
+            UH_TR(4);
         } else {                                                        // ---- path C2: clipped gather (far field)
+            UH_TR(2); UH_TRV(5, 3); UH_TRV(6, 0);
 #pragma unroll
             for (int k0 = 0; k0 < STEPS; k0 += BT_F) {
                 Pix<C> Ia[BT_F], Ib[BT_F], Ic[BT_F], Id[BT_F];
@@ -389,8 +415,13 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
                 }
                 if (BT_F < STEPS) __builtin_amdgcn_sched_barrier(0);
             }
+            UH_TR(3); UH_TR(4);
         }
     }
+#ifdef UH_WARP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // stores acknowledged
+    UH_TR(7);
+#endif
     if (TPB_F > 1) {                    // the next tile's DMA must not overtake this tile's LDS reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -910,6 +941,12 @@ extern "C" int uh_warp_patch_backward(const float* U, const float* theta, const 
     }
     return (int)hipGetLastError();
 }
+
+#ifdef UH_WARP_TRACE
+extern "C" __attribute__((visibility("default"))) int uh_debug_set_trace(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(uh::g_trace), &p, sizeof(p));
+}
+#endif
 
 extern "C" int uh_warp_forward_literal(const float* U, const float* theta, float* out, int B, int H, int W, int C,
                                        int oh, int ow, uh_stream_t stream) {

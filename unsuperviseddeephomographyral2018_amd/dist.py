@@ -64,6 +64,12 @@ class GradAverager(object):
         self.buckets = []
         self._handles = []
         self._hooks = []
+        # RCCL ("nccl") averages in the collective itself (ReduceOp.AVG): no separate 137 MB divide pass after the wait.
+        # gloo (CPU tests) has no AVG: SUM + div_.
+        self._avg_in_collective = bool(self.world > 1 and dist.is_initialized() and dist.get_backend() == 'nccl')
+        self._op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        self.exposed_wait_s = 0.0          # host time finish() spent blocked on the collectives (what backward did not hide)
+        self.finishes = 0
         for plist in (b0, b1):
             if not plist:
                 continue
@@ -88,7 +94,7 @@ class GradAverager(object):
         def hook(param):
             bucket['pending'] -= 1
             if bucket['pending'] == 0 and self.world > 1:
-                self._handles.append(dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, async_op=True))
+                self._handles.append(dist.all_reduce(bucket['flat'], op=self._op, async_op=True))
         return hook
 
     def reset(self):
@@ -106,14 +112,41 @@ class GradAverager(object):
     def finish(self):
         """Call after backward, before optimizer.step(): wait for the all-reduces and divide by world."""
         if self.world > 1:
+            import time
             for b in self.buckets:
                 if b['pending'] != 0:          # a parameter received no gradient: reduce it now
-                    self._handles.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True))
+                    self._handles.append(dist.all_reduce(b['flat'], op=self._op, async_op=True))
+            t0 = time.perf_counter()
             for h in self._handles:
                 h.wait()
-            for b in self.buckets:
-                b['flat'].div_(self.world)
+            self.exposed_wait_s += time.perf_counter() - t0
+            self.finishes += 1
+            if not self._avg_in_collective:
+                for b in self.buckets:
+                    b['flat'].div_(self.world)
         self._handles = []
+
+    def time_buckets(self, iters=5):
+        """Stand-alone duration of each bucket's all-reduce (barrier + device sync either side, `iters` repeats): what the
+        exchange step costs when nothing hides it.  -> [{'bytes', 'ms', 'algbw_GBs', 'busbw_GBs'}] (rank-local view)."""
+        import time
+        out = []
+        for b in self.buckets:
+            buf = torch.empty_like(b['flat'])
+            dist.all_reduce(buf, op=self._op)                      # warm-up (communicator / buffers)
+            if buf.is_cuda:
+                torch.cuda.synchronize(buf.device)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                dist.all_reduce(buf, op=self._op)
+            if buf.is_cuda:
+                torch.cuda.synchronize(buf.device)
+            dt = (time.perf_counter() - t0) / iters
+            nbytes = buf.numel() * buf.element_size()
+            out.append({'bytes': nbytes, 'ms': round(dt * 1e3, 4), 'algbw_GBs': round(nbytes / dt / 1e9, 1),
+                        'busbw_GBs': round(nbytes / dt / 1e9 * 2 * (self.world - 1) / self.world, 1)})
+        return out
 
     def remove(self):
         for h in self._hooks:

@@ -120,6 +120,14 @@ class TrainStep(object):
         self.averager = uh_dist.GradAverager(self.net, world) if world > 1 else None
         kw = {}
         self.step_graph = bool(getattr(args, 'step_graph', False)) and device.type == 'cuda' and world == 1
+        if getattr(args, 'step_graph', False) and world > 1:
+            import warnings
+            warnings.warn('--step_graph is ignored with world size %d: the RCCL all-reduces are issued from autograd hooks '
+                          'and are not captured; running the eager step' % world)
+        # bench / test hook: per-pair corner offsets ADDED to the regressor's output (None = off).  bench.py sets
+        # gt + N(0, 2 px) so that theta in the timed steps follows SURVEY section 8(d)'s mid-training law instead of the
+        # near-identity a 25-step-old regressor predicts; the step itself (conv fwd/bwd, hot path, Adam) is unchanged.
+        self.h4p_offset = None
         lr0 = args.lr
         if device.type == 'cuda':
             kw['fused'] = True
@@ -152,14 +160,27 @@ class TrainStep(object):
                 g['lr'] = lr
 
     def _capture(self, batch):
+        import copy
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        # The eager warm-up below (MIOpen find, allocator, Adam state creation) must not count as training: snapshot the
+        # variables, the optimizer state and the RNG streams (dropout) and put them back, so that step k of a
+        # --step_graph run sees exactly what step k of an eager run sees.
+        net_sd = copy.deepcopy(self.net.state_dict())
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):                    # eager warm-up on a side stream (MIOpen find, allocator, Adam state)
+        with torch.cuda.stream(side):
             for _ in range(3):
                 self._forward_backward_update(self._static)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        self.net.load_state_dict(net_sd)
+        with torch.no_grad():                            # Adam: keep the (capturable) state tensors, zero their contents
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.set_rng_state(rng_cpu); torch.cuda.set_rng_state(rng_dev, self.device)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._graph_model = self._forward_backward_update(self._static)
@@ -173,7 +194,8 @@ class TrainStep(object):
     def _forward_backward_update(self, batch):
         self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
-                                net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64)
+                                net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
+                                h4p_offset=self.h4p_offset)
         model.loss.backward()
         if self.averager is not None:
             self.averager.finish()
@@ -185,8 +207,7 @@ class TrainStep(object):
         if self.step_graph:
             self._set_lr()
             if self._graph is None:
-                self._capture(batch)                     # includes 3 eager warm-up steps
-                self.global_step += 3
+                self._capture(batch)                     # its eager warm-up steps are rolled back
             for k, v in batch.items():                   # new data lands in the static buffers the graph reads
                 if torch.is_tensor(v) and v.data_ptr() != self._static[k].data_ptr():
                     self._static[k].copy_(v)
@@ -211,7 +232,7 @@ class TrainStep(object):
         self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
-                                graph_tail=getattr(self.args, 'graph_tail', False))
+                                graph_tail=getattr(self.args, 'graph_tail', False), h4p_offset=self.h4p_offset)
         model.loss.backward()
         if self.averager is not None:
             self.averager.finish()

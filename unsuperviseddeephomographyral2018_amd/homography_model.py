@@ -120,7 +120,8 @@ def reset_variables():
 
 class HomographyModel(object):
     def __init__(self, args, I1, I2, I1_aug, I2_aug, I_aug, I_prime_aug, h4p, gt, patch_indices,
-                 reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False, graph_tail=False):
+                 reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False, graph_tail=False,
+                 h4p_offset=None):
         self.params = args
         self.mode = args.mode
         self.is_training = True if self.mode == 'train' else False
@@ -140,6 +141,7 @@ class HomographyModel(object):
         # MI355X-side switches (not in the reference): fused patch kernel for the l1 path, f64 DLT solve
         self.fused_patch = fused_patch
         self.solve_f64 = solve_f64
+        self.h4p_offset = h4p_offset        # [B,8] added to the regressor's output (bench / test hook; None = off)
         # one library call / one hipGraph launch for solve_DLT + transform + l1 loss and their backward (l1_loss only)
         self.graph_tail = bool(graph_tail) and args.loss_type == 'l1_loss'
         if args.loss_type not in LOSS_TYPES:
@@ -177,6 +179,8 @@ class HomographyModel(object):
 
     def _vgg(self):
         self.pred_h4p = self.net(self.model_input)                # BATCH_SIZE x 8
+        if self.h4p_offset is not None:
+            self.pred_h4p = self.pred_h4p + self.h4p_offset
 
     # ---- homography_model.py:169-250 (+ the theta fold of :254) ------------------------------------
     def solve_DLT(self):
