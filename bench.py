@@ -53,6 +53,9 @@ def parse():
     ap.add_argument('--cpu_baseline', type=int, default=1)
     ap.add_argument('--north_star', type=int, default=1, help='0: skip the extra warp-only measurement at batch 128')
     ap.add_argument('--config4', type=int, default=1, help='0: skip the extra warp-only measurement at BASELINE configs[3] (480x640, rho 64, batch 128)')
+    ap.add_argument('--only_points', default='', help='"config4", "north_star" or "config4,north_star": measure only those '
+                    'warp-only points and print them as one JSON line (used under rocprofv3 so that the kernel-trace stats '
+                    'hold one shape per kernel name)')
     ap.add_argument('--mid_training_theta', type=int, default=1,
                     help='1: add gt + N(0, 2 px) to the regressor output inside the timed steps, so that theta follows SURVEY '
                          '8(d)\'s mid-training law (perspective, clipped and far-field tiles) instead of the near-identity a '
@@ -178,6 +181,22 @@ def warp_point(device, B, H, W, P, rho, iters=20, seed=7):
             'timing': 'HIP start/stop events of each dispatch (uh_profile_*), %d launches' % iters}
 
 
+def committed_traffic(key):
+    """HBM bytes per launch from the committed PMC file (profiles/traffic_rNN.json) -- NOT measured in this run."""
+    for name in ('traffic_r02.json', 'traffic_r01.json'):
+        f = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(f):
+            try:
+                tr = json.load(open(f))
+            except Exception:
+                continue
+            if key in tr:
+                return {'hbm_bytes_per_launch': tr[key]['hbm_bytes_per_launch'], 'file': 'profiles/' + name,
+                        'provenance': tr.get('_provenance', 'no provenance recorded'),
+                        'note': 'read from the committed file, not measured in this run'}
+    return None
+
+
 def north_star_point(device, args):
     """north_star's point: batch 128, 240x320 (working set 354 MB: partly Infinity-Cache resident)."""
     return warp_point(device, 128, args.img_h, args.img_w, args.patch_size, args.rho, iters=30)
@@ -186,7 +205,10 @@ def north_star_point(device, args):
 def config4_point(device, args):
     """BASELINE.json configs[3]: full-frame 480x640 warp, rho = 64, batch 128 -- 1.9 GB working set, far beyond the
     256 MB Infinity Cache: the HBM-resident roofline point."""
-    return warp_point(device, 128, 480, 640, args.patch_size, 64, iters=20)
+    r = warp_point(device, 128, 480, 640, args.patch_size, 64, iters=20)
+    r['traffic_fwd'] = committed_traffic('warp_forward_B128_480x640')
+    r['traffic_bwd'] = committed_traffic('warp_backward_B128_480x640')
+    return r
 
 
 def main():
@@ -205,6 +227,15 @@ def main():
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = True                   # MIOpen find: pick the fastest f32 conv solvers
     torch.manual_seed(1234)
+
+    if args.only_points:
+        out = {}
+        if 'north_star' in args.only_points:
+            out['north_star_point'] = north_star_point(device, args)
+        if 'config4' in args.only_points:
+            out['config4_point'] = config4_point(device, args)
+        print(json.dumps(out), flush=True)
+        return
 
     B = args.per_gpu_batch
     targs = build_parser().parse_args([

@@ -62,7 +62,7 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert lib.uh_patch_losses_forward(one, one, one, None, one, one, 1 << 20, 2, 16, None) == -1   # h4p xor gt
     assert lib.uh_patch_losses_forward(one, one, None, None, one, one, 1 << 20, 2, 2, None) == -2   # P < 3 (3x3 SSIM window)
     assert lib.uh_patch_losses_forward(one, one, None, None, one, None, 0, 2, 16, None) == -4
-    assert lib.uh_patch_losses_workspace_bytes(64, 128) == 64 * 64 * 7 * 4
+    assert lib.uh_patch_losses_workspace_bytes(64, 128) == 64 * 16 * 7 * 4
     assert lib.uh_patch_loss_backward(7, one, one, one, one, one, 2, 16, None) == -2             # unknown loss kind
     assert lib.uh_patch_loss_backward(1, one, one, None, one, one, 2, 16, None) == -1
     assert lib.uh_warp_patch_backward(one, one, one, one, one, None, 0, 2, 16, 16, 3, 64, None) == -4

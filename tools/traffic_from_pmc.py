@@ -1,13 +1,16 @@
 #!/usr/bin/env python
-"""rocprofv3 counter_collection CSVs of `bench.py` (FETCH_SIZE pass + WRITE_SIZE pass) -> profiles/traffic_r01.json.
+"""rocprofv3 counter_collection CSVs of `bench.py` (FETCH_SIZE pass + WRITE_SIZE pass) -> profiles/traffic_rNN.json.
 
 HBM bytes per launch = FETCH_SIZE[KiB] * 1024 * 2  +  WRITE_SIZE[KiB] * 1024
   * x2 on FETCH_SIZE: gfx950 tallies a 128-byte fabric read request as 64 bytes (MI355X_MICROARCH.md, "HBM");
     re-calibrated in this repo on a device copy of known size (profiles/r01a_pmc_*: copy of 471.9 MB -> FETCH_SIZE
     230.4 MiB, WRITE_SIZE 471.9 MB; TCC_EA0_RDREQ x 128 B and TCC_EA0_WRREQ x 64 B give the same bytes).
-usage: traffic_from_pmc.py <pmc_dir> <B> <H> <W> <out.json> <label>"""
+usage: traffic_from_pmc.py <pmc_dir> <B> <H> <W> <out.json> <label> [provenance]"""
 import csv, glob, json, re, sys, collections
 d, B, H, W, out, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6]
+prov = sys.argv[7] if len(sys.argv) > 7 else ''
+import os
+name = os.path.basename(out)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -29,7 +32,9 @@ for k, cs in acc.items():
     res['%s_B%d_%dx%d' % (k, B, H, W)] = {
         'hbm_bytes_per_launch': int(fs * 1024 * 2 + ws * 1024), 'FETCH_SIZE_KiB_median': fs, 'WRITE_SIZE_KiB_median': ws,
         'launches_seen': len(cs['FETCH_SIZE']),
-        'source': 'profiles/traffic_r01.json <- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `%s`; '
+        'source': 'profiles/' + name + ' <- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `%s`; '
                   'bytes = FETCH_SIZE*2 KiB + WRITE_SIZE KiB (gfx950 correction, calibrated on a device copy)' % label}
+if prov:
+    res['_provenance'] = prov
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))

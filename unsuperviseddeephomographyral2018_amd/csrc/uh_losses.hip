@@ -19,6 +19,7 @@
 namespace uh {
 
 constexpr int NLS = 7;      // |d|, d^2, smooth-l1, x^2, y^2, x*y, ssim
+constexpr int LPT = 4;      // patch pixels per thread of patch_losses_kernel
 
 // one thread per patch pixel (i, j): its point-wise terms, plus the SSIM of the 3x3 window whose top-left
 // corner it is (i, j < P-2).  The 2 x 9 window taps come from L1/L2 (the patch is 64 KiB per image).
@@ -33,14 +34,17 @@ __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restri
     float acc[NLS];
 #pragma unroll
     for (int k = 0; k < NLS; ++k) acc[k] = 0.f;
-    const int e = chunk * 256 + (int)threadIdx.x;
+    // LPT pixels per thread: 4x fewer partial rows for the one-block finish to walk (it was the slowest launch of the tail)
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+    const int e = (chunk * LPT + q) * 256 + (int)threadIdx.x;
     if (e < n) {
         const int i = e / P, j = e - i * P;
         const float xv = x[e], yv = y[e];
         const float d = xv - yv, ad = fabsf(d);
-        acc[0] = ad; acc[1] = d * d;
-        acc[2] = ad < 1.0f ? 0.5f * (ad * ad) : ad - 0.5f;
-        acc[3] = xv * xv; acc[4] = yv * yv; acc[5] = xv * yv;
+        acc[0] += ad; acc[1] += d * d;
+        acc[2] += ad < 1.0f ? 0.5f * (ad * ad) : ad - 0.5f;
+        acc[3] += xv * xv; acc[4] += yv * yv; acc[5] += xv * yv;
         if (i < P - 2 && j < P - 2) {
             float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
 #pragma unroll
@@ -55,8 +59,9 @@ __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restri
             const float sgx = sxx * inv9 - mux * mux, sgy = syy * inv9 - muy * muy, sgxy = sxy * inv9 - mux * muy;
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             const float ssim = ((2.f * mux * muy + C1) * (2.f * sgxy + C2)) / ((mux * mux + muy * muy + C1) * (sgx + sgy + C2));
-            acc[6] = fminf(fmaxf((1.f - ssim) * 0.5f, 0.f), 1.f);
+            acc[6] += fminf(fmaxf((1.f - ssim) * 0.5f, 0.f), 1.f);
         }
+    }
     }
 #pragma unroll
     for (int k = 0; k < NLS; ++k) {
@@ -226,7 +231,7 @@ using namespace uh;
 
 extern "C" size_t uh_patch_losses_workspace_bytes(int B, int P) {
     if (B <= 0 || P <= 0) return 0;
-    return (size_t)B * ((P * P + 255) / 256) * NLS * sizeof(float);
+    return (size_t)B * ((P * P + 256 * LPT - 1) / (256 * LPT)) * NLS * sizeof(float);
 }
 
 extern "C" int uh_patch_loss_backward(int kind, const float* pred, const float* target, const float* stats16,
@@ -260,7 +265,7 @@ extern "C" int uh_patch_losses_forward(const float* pred, const float* target, c
     if (B <= 0 || P < 3) return UH_E_SHAPE;
     if ((uint64_t)B * P * P >= (1ull << 31)) return UH_E_TOO_LARGE;
     if (!workspace || workspace_bytes < uh_patch_losses_workspace_bytes(B, P)) return UH_E_WORKSPACE;
-    const int bpi = (P * P + 255) / 256;
+    const int bpi = (P * P + 256 * LPT - 1) / (256 * LPT);
     hipStream_t s = (hipStream_t)stream;
     launch_timed(UH_K_LOSSES, patch_losses_kernel, dim3((unsigned)B * bpi), dim3(256), s, pred, target, (float*)workspace, P, bpi);
     hipError_t e = hipGetLastError();

@@ -91,16 +91,15 @@ __global__ __launch_bounds__(256) void warp_patch_l1_kernel(
             acc[9] += m * fabsf(d);
             if (WANT_GRAD) {
                 const float sgn = d > 0.f ? m : (d < 0.f ? -m : 0.f);
-                float ex = 0.f, ey = 0.f;
-                // lerp form of ay1 (Ic-Ia) + ay0 (Id-Ib): exact 0 where the clip collapsed a pair (see uh_warp.hip)
-                const float hx = s[k].hx, hy = s[k].hy;
+                // lerp form of ay1 (Ic-Ia) + ay0 (Id-Ib) with the shared second difference u: exact 0 where the clip
+                // collapsed a pair (see accumulate() in uh_warp.hip)
+                float s1 = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const float dca = Ic[k].v[c] - Ia[k].v[c], ddb = Id[k].v[c] - Ib[k].v[c];
-                    const float dba = Ib[k].v[c] - Ia[k].v[c], ddc = Id[k].v[c] - Ic[k].v[c];
-                    ex += fmaf(s[k].ay1, dca - ddb, hy * ddb);
-                    ey += fmaf(s[k].ax1, dba - ddc, hx * ddc);
+                    const float ddb = Id[k].v[c] - Ib[k].v[c], ddc = Id[k].v[c] - Ic[k].v[c];
+                    s1 += (Ic[k].v[c] - Ia[k].v[c]) - ddb; sb += ddb; sc += ddc;
                 }
+                const float ex = fmaf(s[k].ay1, s1, s[k].hy * sb), ey = fmaf(s[k].ax1, s1, s[k].hx * sc);
                 const float gg = sgn / (float)C;
                 const float rt = s[k].rt;
                 const float dxs = gg * ex * halfW * rt, dys = gg * ey * halfH * rt;

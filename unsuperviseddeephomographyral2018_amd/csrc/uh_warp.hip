@@ -83,7 +83,10 @@ static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the ste
                                   // (6 x 4 waves x 6 KiB LDS slices = 144 KiB of the CU's 160 KiB; 80 VGPRs, no spill)
 #endif
 #ifndef UH_WARP_BWD_MINW
-#define UH_WARP_BWD_MINW 1
+#define UH_WARP_BWD_MINW 5        // 96 VGPRs without path C1 (no spill)
+#endif
+#ifndef UH_WARP_BWD_C1
+#define UH_WARP_BWD_C1 0          // backward: staged clipped path off (see the kernel)
 #endif
 static_assert(UH_WARP_STEPS_BWD % UH_WARP_BWD_BATCH == 0, "batch must divide the steps");
 constexpr int NWAVE = 4;                // waves per block, side by side in x: block tile = (4*TW) x TH
@@ -137,20 +140,24 @@ __device__ __forceinline__ Extent wave_extent(const float (&fx)[N], const float 
     return e;
 }
 
-// The same for a wave with clipped taps: exact extent of the CLIPPED corners (non-negative integers held in f32).
+// The same for a wave with clipped taps: exact extent of the CLIPPED corners (non-negative integers held in f32),
+// ... computed straight from the pixel coordinates: the clipped corners are formed, folded into the running min / max
+// and dropped (the clipped paths re-derive them per pixel: 12 cheap VALU ops instead of 4 live VGPRs per pixel).
 template <int N>
-__device__ __forceinline__ Extent wave_extent_clipped(const float (&x0f)[N], const float (&x1f)[N], const float (&y0f)[N],
-                                                      const float (&y1f)[N]) {
-    int mnx = __float_as_int(x0f[0]), mxx = __float_as_int(x1f[0]), mny = __float_as_int(y0f[0]), mxy = __float_as_int(y1f[0]);
+__device__ __forceinline__ Extent wave_extent_clipped_xy(const Proj (&p)[N], const SrcGeom& g) {
+    int mnx = 0x7fffffff, mxx = 0, mny = 0x7fffffff, mxy = 0;
 #pragma unroll
-    for (int k = 1; k < N; ++k) {
-        mnx = min(mnx, __float_as_int(x0f[k])); mxx = max(mxx, __float_as_int(x1f[k]));
-        mny = min(mny, __float_as_int(y0f[k])); mxy = max(mxy, __float_as_int(y1f[k]));
+    for (int k = 0; k < N; ++k) {
+        float a0, a1, b0, b1;
+        clip_pair(p[k].x, g.Wm1, a0, a1);
+        clip_pair(p[k].y, g.Hm1, b0, b1);
+        mnx = min(mnx, __float_as_int(a0)); mxx = max(mxx, __float_as_int(a1));
+        mny = min(mny, __float_as_int(b0)); mxy = max(mxy, __float_as_int(b1));
     }
     mnx = wave_min_nonneg(mnx); mxx = wave_max_nonneg(mxx);
     mny = wave_min_nonneg(mny); mxy = wave_max_nonneg(mxy);
     Extent e;
-    e.interior = true;                       // (meaning here: the rectangle below holds every tap of the wave)
+    e.interior = true;
     e.bx0 = (int)__int_as_float(mnx); e.by0 = (int)__int_as_float(mny);
     e.rw = (int)__int_as_float(mxx) - e.bx0 + 1; e.rh = (int)__int_as_float(mxy) - e.by0 + 1;
     return e;
@@ -366,19 +373,19 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
             UH_TR(3); UH_TR(4);
         }
     } else {                                                            // ---- some tap is clipped
-        float x0f[STEPS], x1f[STEPS], y0f[STEPS], y1f[STEPS];
-#pragma unroll
-        for (int k = 0; k < STEPS; ++k) {                               // fx / fy are dead from here on
-            clip_pair(p[k].x, g.Wm1, x0f[k], x1f[k]);                                           // (:101-109)
-            clip_pair(p[k].y, g.Hm1, y0f[k], y1f[k]);
-        }
         Stage st;
         st.fits = false;
         Extent ec;
-        if constexpr (STAGE_FWD) { ec = wave_extent_clipped<STEPS>(x0f, x1f, y0f, y1f); st = plan_stage<C, LDSW>(ec); }
+        if constexpr (STAGE_FWD) { ec = wave_extent_clipped_xy<STEPS>(p, g); st = plan_stage<C, LDSW>(ec); }
 #ifdef UH_WARP_NO_C1               // developer A/B switch: clipped waves always gather
         st.fits = false;
 #endif
+        auto corners = [&](int k) {                                     // floor / clip of pixel k (fx / fy are dead here) (:101-109)
+            Coord c;
+            clip_pair(p[k].x, g.Wm1, c.x0f, c.x1f);
+            clip_pair(p[k].y, g.Hm1, c.y0f, c.y1f);
+            return c;
+        };
         if (STAGE_FWD && st.fits) {                                     // ---- path C1: clipped rectangle through LDS
             stage_dma<C, LDSW>(rin, lds, lane, ec, st, g.rowBi);
             UH_TR(2); UH_TRV(5, 2); UH_TRV(6, st.nld);
@@ -386,12 +393,11 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
             UH_TR(3);
 #pragma unroll
             for (int k = 0; k < STEPS; ++k) {
-                Coord c;
-                c.x0f = x0f[k]; c.x1f = x1f[k]; c.y0f = y0f[k]; c.y1f = y1f[k];
+                const Coord c = corners(k);
                 const TapOff o = staged_offsets(c, st.pitch, g.pixB, st.nbase);
                 const Pix<C> Ia = lds_load<C>(lds, o.oa), Ib = lds_load<C>(lds, o.ob);
                 const Pix<C> Ic = lds_load<C>(lds, o.oc), Id = lds_load<C>(lds, o.od);
-                emit(k, x1f[k] - p[k].x, p[k].x - x0f[k], y1f[k] - p[k].y, p[k].y - y0f[k], Ia, Ib, Ic, Id);   // (:130-137)
+                emit(k, c.x1f - p[k].x, p[k].x - c.x0f, c.y1f - p[k].y, p[k].y - c.y0f, Ia, Ib, Ic, Id);       // (:130-137)
             }
             UH_TR(4);
         } else {                                                        // ---- path C2: clipped gather (far field)
@@ -399,19 +405,18 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
 #pragma unroll
             for (int k0 = 0; k0 < STEPS; k0 += BT_F) {
                 Pix<C> Ia[BT_F], Ib[BT_F], Ic[BT_F], Id[BT_F];
+                Coord c[BT_F];
 #pragma unroll
                 for (int j = 0; j < BT_F; ++j) {
-                    const int k = k0 + j;
-                    Coord c;
-                    c.x0f = x0f[k]; c.x1f = x1f[k]; c.y0f = y0f[k]; c.y1f = y1f[k];
-                    const TapOff o = global_offsets<SMALL>(c, g);
+                    c[j] = corners(k0 + j);
+                    const TapOff o = global_offsets<SMALL>(c[j], g);
                     Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
                     Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < BT_F; ++j) {
                     const int k = k0 + j;
-                    emit(k, x1f[k] - p[k].x, p[k].x - x0f[k], y1f[k] - p[k].y, p[k].y - y0f[k], Ia[j], Ib[j], Ic[j], Id[j]);
+                    emit(k, c[j].x1f - p[k].x, p[k].x - c[j].x0f, c[j].y1f - p[k].y, p[k].y - c[j].y0f, Ia[j], Ib[j], Ic[j], Id[j]);
                 }
                 if (BT_F < STEPS) __builtin_amdgcn_sched_barrier(0);
             }
@@ -525,19 +530,22 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
         // hx = x1f - x0f, hy = y1f - y0f (1 for an interior sample, 0 where the clip collapsed the pair).  With
         // ay0 = hy - ay1:  ay1 (Ic-Ia) + ay0 (Id-Ib) = ay1 [(Ic-Ia) - (Id-Ib)] + hy (Id-Ib)  -- the form used here: a
         // sample whose y pair collapsed has Ic-Ia == Id-Ib and hy == 0 and contributes EXACTLY 0 although |ay| reaches
-        // 1e7 px there (the literal form leaves eps*|ay|*|dI| of cancellation noise per far-field sample).
+        // 1e7 px there (the literal form leaves eps*|ay|*|dI| of cancellation noise per far-field sample); likewise
+        // for x.
         auto accumulate = [&](int k, float ax1, float ay1, float hx, float hy, const Pix<C>& Ia, const Pix<C>& Ib,
                               const Pix<C>& Ic, const Pix<C>& Id) {
-            float dx = 0.f, dy = 0.f;
+            // (Ic-Ia) - (Id-Ib) == (Ib-Ia) - (Id-Ic) =: u (the mixed second difference), so with the channel sums
+            // S1 = sum g u, Sb = sum g (Id-Ib), Sc = sum g (Id-Ic):   dx = ay1 S1 + hy Sb,   dy = ax1 S1 + hx Sc
+            float s1 = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
-                const float dca = Ic.v[ch] - Ia.v[ch], ddb = Id.v[ch] - Ib.v[ch];
-                const float dba = Ib.v[ch] - Ia.v[ch], ddc = Id.v[ch] - Ic.v[ch];
-                const float ex = fmaf(ay1, dca - ddb, hy * ddb);
-                const float ey = fmaf(ax1, dba - ddc, hx * ddc);
-                dx = fmaf(G[k].v[ch], ex, dx);
-                dy = fmaf(G[k].v[ch], ey, dy);
+                const float ddb = Id.v[ch] - Ib.v[ch], ddc = Id.v[ch] - Ic.v[ch];
+                const float u = (Ic.v[ch] - Ia.v[ch]) - ddb;
+                s1 = fmaf(G[k].v[ch], u, s1);
+                sb = fmaf(G[k].v[ch], ddb, sb);
+                sc = fmaf(G[k].v[ch], ddc, sc);
             }
+            const float dx = fmaf(ay1, s1, hy * sb), dy = fmaf(ax1, s1, hx * sc);
             const float rt = p[k].rt;
             const float dxs = dx * halfW * rt, dys = dy * halfH * rt;
             const float dt = -(dxs * p[k].xs + dys * p[k].ys) * rt;
@@ -613,53 +621,61 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                 }
             }
         } else {                                                        // ---- some tap is clipped
-            float x0f[STEPS_B], x1f[STEPS_B], y0f[STEPS_B], y1f[STEPS_B];
-#pragma unroll
-            for (int k = 0; k < STEPS_B; ++k) {
-                clip_pair(p[k].x, g.Wm1, x0f[k], x1f[k]);
-                clip_pair(p[k].y, g.Hm1, y0f[k], y1f[k]);
-            }
             Stage st;
             st.fits = false;
             Extent ec;
-            if constexpr (STAGE_BWD) { ec = wave_extent_clipped<STEPS_B>(x0f, x1f, y0f, y1f); st = plan_stage<C, LDSW>(ec); }
+            // C1 costs the backward 27 VGPRs (123 vs 96: 4 instead of 5 waves per SIMD) and measured no faster than the
+            // gather there (profiles/r02_*), so clipped waves of the backward always gather unless UH_WARP_BWD_C1=1
+            if constexpr (STAGE_BWD && UH_WARP_BWD_C1) { ec = wave_extent_clipped_xy<STEPS_B>(p, g); st = plan_stage<C, LDSW>(ec); }
 #ifdef UH_WARP_NO_C1
             st.fits = false;
 #endif
-            auto corners = [&](int k) { Coord c; c.x0f = x0f[k]; c.x1f = x1f[k]; c.y0f = y0f[k]; c.y1f = y1f[k]; return c; };
-            if (STAGE_BWD && st.fits) {                                 // ---- path C1: clipped rectangle through LDS
+            auto corners = [&](int k) {                                 // floor / clip of pixel k              (:101-109)
+                Coord c;
+                clip_pair(p[k].x, g.Wm1, c.x0f, c.x1f);
+                clip_pair(p[k].y, g.Hm1, c.y0f, c.y1f);
+                return c;
+            };
+            if (STAGE_BWD && UH_WARP_BWD_C1 && st.fits) {               // ---- path C1: clipped rectangle through LDS
                 stage_dma<C, LDSW>(rin, lds, lane, ec, st, g.rowBi);
                 stage_wait();
 #pragma unroll
                 for (int k = 0; k < STEPS_B; ++k) {
-                    const TapOff o = staged_offsets(corners(k), st.pitch, g.pixB, st.nbase);
+                    const Coord c = corners(k);
+                    const TapOff o = staged_offsets(c, st.pitch, g.pixB, st.nbase);
                     const Pix<C> Ia = lds_load<C>(lds, o.oa), Ib = lds_load<C>(lds, o.ob);
                     const Pix<C> Ic = lds_load<C>(lds, o.oc), Id = lds_load<C>(lds, o.od);
-                    accumulate(k, x1f[k] - p[k].x, y1f[k] - p[k].y, x1f[k] - x0f[k], y1f[k] - y0f[k], Ia, Ib, Ic, Id);
+                    accumulate(k, c.x1f - p[k].x, c.y1f - p[k].y, c.x1f - c.x0f, c.y1f - c.y0f, Ia, Ib, Ic, Id);
+                    __builtin_amdgcn_sched_barrier(0);                  // one pixel's taps live at a time (VGPR budget)
                 }
             } else {                                                    // ---- path C2: clipped gather (far field)
 #pragma unroll
                 for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
                     Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];             // 4*BT_B gathers in flight
+                    Coord c[BT_B];
 #pragma unroll
                     for (int j = 0; j < BT_B; ++j) {
-                        const TapOff o = global_offsets<SMALL>(corners(k0 + j), g);
+                        c[j] = corners(k0 + j);
+                        const TapOff o = global_offsets<SMALL>(c[j], g);
                         Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
                         Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
                     }
 #pragma unroll
                     for (int j = 0; j < BT_B; ++j) {
                         const int k = k0 + j;
-                        accumulate(k, x1f[k] - p[k].x, y1f[k] - p[k].y, x1f[k] - x0f[k], y1f[k] - y0f[k], Ia[j], Ib[j], Ic[j], Id[j]);
+                        accumulate(k, c[j].x1f - p[k].x, c[j].y1f - p[k].y, c[j].x1f - c[j].x0f, c[j].y1f - c[j].y0f,
+                                   Ia[j], Ib[j], Ic[j], Id[j]);
                     }
                     if (BT_B < STEPS_B) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (WANT_DU) {
 #pragma unroll
-                for (int k = 0; k < STEPS_B; ++k)
-                    scatter(k, global_offsets<SMALL>(corners(k), g), x1f[k] - p[k].x, p[k].x - x0f[k], y1f[k] - p[k].y,
-                            p[k].y - y0f[k], x1f[k] != x0f[k] && y1f[k] != y0f[k]);
+                for (int k = 0; k < STEPS_B; ++k) {
+                    const Coord c = corners(k);
+                    scatter(k, global_offsets<SMALL>(c, g), c.x1f - p[k].x, p[k].x - c.x0f, c.y1f - p[k].y, p[k].y - c.y0f,
+                            c.x1f != c.x0f && c.y1f != c.y0f);
+                }
             }
         }
     }
@@ -766,14 +782,14 @@ __global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* 
                     const size_t ia = ((size_t)c.y0f * W + (size_t)c.x0f) * C, ib = ((size_t)c.y1f * W + (size_t)c.x0f) * C;
                     const size_t ic = ((size_t)c.y0f * W + (size_t)c.x1f) * C, id = ((size_t)c.y1f * W + (size_t)c.x1f) * C;
                     const float hx = c.x1f - c.x0f, hy = c.y1f - c.y0f;
-                    float dx = 0.f, dy = 0.f;
+                    float s1 = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
                         const float Ia = Ub[ia + ch], Ib = Ub[ib + ch], Ic = Ub[ic + ch], Id = Ub[id + ch];
-                        const float dca = Ic - Ia, ddb = Id - Ib, dba = Ib - Ia, ddc = Id - Ic;
-                        dx = fmaf(gv, fmaf(c.ay1, dca - ddb, hy * ddb), dx);
-                        dy = fmaf(gv, fmaf(c.ax1, dba - ddc, hx * ddc), dy);
+                        const float ddb = Id - Ib, ddc = Id - Ic, u = (Ic - Ia) - ddb;
+                        s1 = fmaf(gv, u, s1); sb = fmaf(gv, ddb, sb); sc = fmaf(gv, ddc, sc);
                     }
+                    const float dx = fmaf(c.ay1, s1, hy * sb), dy = fmaf(c.ax1, s1, hx * sc);
                     const float dxs = dx * halfW * c.rt, dys = dy * halfH * c.rt;
                     const float dt = -(dxs * c.xs + dys * c.ys) * c.rt;
                     acc[0] += (double)dxs * gx; acc[1] += (double)dxs * gy; acc[2] += (double)dxs;
