@@ -29,6 +29,7 @@
 //     neighbouring rectangles is served by that XCD's L2.
 #include "uh_device.h"
 #include "uh_host.h"
+#include <algorithm>
 
 namespace uh {
 
@@ -458,7 +459,15 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
 // the rectangle anchored at patch_idx[k,0] and whose stored index confirms it.  Entries that are not at their rectangle
 // position (arbitrary gathers, duplicates) are counted and handled one by one in the finish kernel, so any index set
 // gives the gradient of uh_gray_patch_backward -> uh_warp_backward; on rectangles the sums are bit-identical to it.
-struct PatchArgs { const int* idx; int P, PP; int* confirmed; };
+// PATCH launches only the block tiles that can touch the rectangle: nrx x nry per image, anchored at the tile holding
+// (x0, y0).  The finish kernel treats every other tile's partial as the 0 the dense kernel would have written there
+// WITHOUT reading it (same summation order, same bits, no memset of the partial buffer).
+struct PatchArgs { const int* idx; int P, PP; int* confirmed; int nrx, nry; };
+__host__ __device__ inline void patch_tile_range(int x0, int y0, int P, int tiles_x, int tiles_y, int th, int& txlo, int& txhi,
+                                                 int& tylo, int& tyhi) {
+    txlo = x0 / (NWAVE * TW); txhi = min((x0 + P - 1) / (NWAVE * TW), tiles_x - 1);
+    tylo = y0 / th;           tyhi = min((y0 + P - 1) / th, tiles_y - 1);
+}
 template <int C, bool WANT_DU, bool SMALL, bool PATCH = false>
 __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
         const float* __restrict__ U, const float* __restrict__ theta, const float* __restrict__ dOut,
@@ -468,20 +477,33 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[STAGE_BWD ? NWAVE * LDSW : 16];
     __shared__ float red[9][NWAVE * 4];
     const int lane = threadIdx.x & 63, wave = wave_id();
-    const unsigned v = xcd_remap(blockIdx.x, nblk);
-    const int b = v / tiles, tile = v - b * tiles;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    unsigned v = xcd_remap(blockIdx.x, nblk);
+    int b, ty, tx;
+    int px0 = 0, py0 = 0;                                                // PATCH: top-left pixel of the patch rectangle
+    if constexpr (PATCH) {
+        const int per = pa.nrx * pa.nry;
+        b = v / per;
+        const int r = v - b * per, j = r / pa.nrx, i = r - j * pa.nrx;
+        const int o = pa.idx[(size_t)b * pa.PP];                         // uniform -> scalar load
+        py0 = o / W; px0 = o - py0 * W;
+        int txlo, txhi, tylo, tyhi;
+        patch_tile_range(px0, py0, pa.P, tiles_x, tiles / tiles_x, TH_B, txlo, txhi, tylo, tyhi);
+        tx = txlo + i; ty = tylo + j;
+        if (pa.P <= 0 || tx > txhi || ty > tyhi) return;                 // whole block: not a tile of this rectangle
+        v = (unsigned)(b * tiles + ty * tiles_x + tx);                   // index of the tile's partial (dense layout)
+    } else {
+        b = v / tiles;
+        const int tile = v - b * tiles;
+        ty = tile / tiles_x; tx = tile - ty * tiles_x;
+    }
     const int col = (tx * NWAVE + wave) * TW + (lane & (TW - 1));
     const int row0 = ty * TH_B + (lane / TW);                              // this lane's first row
     float acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = 0.f;
     int nconf = 0;                                                       // PATCH: entries this lane confirmed
-    int px0 = 0, py0 = 0;                                                // PATCH: top-left pixel of the patch rectangle
     bool live = (tx * NWAVE + wave) * TW < ow;                           // wave-uniform; else the wave adds 0
     if constexpr (PATCH) {
-        const int o = pa.idx[(size_t)b * pa.PP];                         // uniform -> scalar load
-        py0 = o / W; px0 = o - py0 * W;
         const int wx0 = (tx * NWAVE + wave) * TW, wy0 = ty * TH_B;
         live = live && wx0 < px0 + pa.P && wx0 + TW > px0 && wy0 < py0 + pa.P && wy0 + TH_B > py0;
     }
@@ -733,7 +755,7 @@ __global__ __launch_bounds__(256) void warp_forward_literal_kernel(const float* 
 // confirmed count falls short of PP, the wave walks the PP entries and samples the stray ones itself (literal path C
 // arithmetic, f64 accumulation, fixed order).  For the dataloader's rectangles nothing is added.
 struct PatchFinish { const float* U; const float* theta; const float* dPred; const int* idx; const int* confirmed;
-                     int P, PP, H, W; float sx, sy; };
+                     int P, PP, H, W; float sx, sy; int tiles_x; };
 template <int C, bool PATCH>
 __global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* __restrict__ partial,
                                                                    float* __restrict__ dTheta, int tiles, int B,
@@ -742,18 +764,30 @@ __global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     double a = 0.0;
+    int txlo = 0, txhi = -1, tylo = 0, tyhi = -1;                        // PATCH: the tiles the bandwidth kernel wrote
+    if constexpr (PATCH) {
+        if (b < B && pf.P > 0) {
+            const int o = pf.idx[(size_t)b * pf.PP];
+            patch_tile_range(o - (o / pf.W) * pf.W, o / pf.W, pf.P, pf.tiles_x, tiles / pf.tiles_x, TH_B, txlo, txhi, tylo, tyhi);
+        }
+    }
+    auto written = [&](int tile) {                                       // every other partial counts as 0 (and is never read)
+        if constexpr (!PATCH) return true;
+        const int ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
+        return tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi;
+    };
     if (b < B && lane < 63) {
         const float* p = partial + (size_t)b * tiles * 9;
         const int n = tiles * 9;
 #pragma unroll 4
-        for (int e = lane; e < n; e += 63) a += (double)p[e];
+        for (int e = lane; e < n; e += 63) a += written(e / 9) ? (double)p[e] : 0.0;
     }
     red[wave][lane] = a;
     double extra = 0.0;                                                  // lane j < 9: stray entries' share of sum j
     if constexpr (PATCH) {
         if (b < B) {                                                     // wave-uniform
             int cnt = 0;
-            for (int e = lane; e < tiles; e += 64) cnt += pf.confirmed[(size_t)b * tiles + e];
+            for (int e = lane; e < tiles; e += 64) cnt += written(e) ? pf.confirmed[(size_t)b * tiles + e] : 0;
             cnt = (int)wave_sum((double)cnt);
             if (cnt != pf.PP) {
                 const int H = pf.H, W = pf.W, P = pf.P, PP = pf.PP;
@@ -874,7 +908,7 @@ static void launch_bwd(const float* U, const float* theta, const float* dOut, fl
     const bool sm = small_image(H, W, C);
 #define UH_BWD(DU, SM) launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, DU, SM, false>, dim3(nblk), dim3(256), s, U, \
                                    theta, dOut, partial, dU, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk, \
-                                   PatchArgs{nullptr, 0, 0, nullptr})
+                                   PatchArgs{nullptr, 0, 0, nullptr, 0, 0})
     if (dU) { if (sm) UH_BWD(true, true); else UH_BWD(true, false); }
     else    { if (sm) UH_BWD(false, true); else UH_BWD(false, false); }
 #undef UH_BWD
@@ -921,15 +955,18 @@ template <int C>
 static void launch_patch_bwd(const float* U, const float* theta, const float* dPred, const int* idx, float* partial,
                              int* confirmed, float* dTheta, int B, int H, int W, int P, int PP, hipStream_t s) {
     const TileGeom g = tile_geom(H, W, TH_B);
-    const unsigned nblk = (unsigned)B * g.tiles;
-    const PatchArgs pa{idx, P, PP, confirmed};
+    // block tiles a P x P rectangle can touch: one more than it spans when aligned
+    const int nrx = P > 0 ? std::min(g.tiles_x, (P - 1) / (NWAVE * TW) + 2) : 1;
+    const int nry = P > 0 ? std::min(g.tiles_y, (P - 1) / TH_B + 2) : 1;
+    const unsigned nblk = (unsigned)B * nrx * nry;
+    const PatchArgs pa{idx, P, PP, confirmed, nrx, nry};
     if (small_image(H, W, C))
         launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, true, true>, dim3(nblk), dim3(256), s, U, theta, dPred,
                      partial, (float*)nullptr, H, W, H, W, lin_step(W), lin_step(H), g.tiles_x, g.tiles, nblk, pa);
     else
         launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, false, true>, dim3(nblk), dim3(256), s, U, theta, dPred,
                      partial, (float*)nullptr, H, W, H, W, lin_step(W), lin_step(H), g.tiles_x, g.tiles, nblk, pa);
-    const PatchFinish pf{U, theta, dPred, idx, confirmed, P, PP, H, W, lin_step(W), lin_step(H)};
+    const PatchFinish pf{U, theta, dPred, idx, confirmed, P, PP, H, W, lin_step(W), lin_step(H), g.tiles_x};
     launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel<C, true>, dim3((B + 3) / 4), dim3(256), s,
                  (const float*)partial, dTheta, g.tiles, B, pf);
 }
