@@ -74,10 +74,6 @@ constexpr int BT_B = UH_WARP_BWD_BATCH;
 #define UH_WARP_FWD_BATCH 2       // forward gather paths (B, C): the same
 #endif
 constexpr int BT_F = UH_WARP_FWD_BATCH;
-#ifndef UH_WARP_FWD_TPB
-#define UH_WARP_FWD_TPB 1         // forward: consecutive tiles one block walks
-#endif
-constexpr int TPB_F = UH_WARP_FWD_TPB;
 static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the steps");
 #ifndef UH_WARP_FWD_MINW
 #define UH_WARP_FWD_MINW 6        // __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow
@@ -85,9 +81,6 @@ static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the ste
 #endif
 #ifndef UH_WARP_BWD_MINW
 #define UH_WARP_BWD_MINW 5        // 96 VGPRs without path C1 (no spill)
-#endif
-#ifndef UH_WARP_BWD_C1
-#define UH_WARP_BWD_C1 0          // backward: staged clipped path off (see the kernel)
 #endif
 static_assert(UH_WARP_STEPS_BWD % UH_WARP_BWD_BATCH == 0, "batch must divide the steps");
 constexpr int NWAVE = 4;                // waves per block, side by side in x: block tile = (4*TW) x TH
@@ -183,16 +176,12 @@ __device__ __forceinline__ Stage plan_stage(const Extent& e) {
     s.nbase = -((float)e.by0 * s.pitch + (float)(e.bx0 * C * 4));
     return s;
 }
-#ifndef UH_WARP_LDS_DMA
-#define UH_WARP_LDS_DMA 1         // 0: stage through VGPRs (buffer_load_dwordx4 + ds_write_b128) -- developer A/B switch
-#endif
 template <int C, int LDS_BYTES>
 __device__ __forceinline__ void stage_dma(__amdgpu_buffer_rsrc_t rin, unsigned char* lds, int lane, const Extent& e,
                                           const Stage& s, int rowBi) {
     const unsigned magic = (65536u + (unsigned)s.cpr - 1u) / (unsigned)s.cpr;     // wave-uniform (SALU)
     const unsigned n = (unsigned)(s.cpr * e.rh);
     const unsigned base = (unsigned)e.by0 * (unsigned)rowBi + (unsigned)(e.bx0 * C * 4);
-#if UH_WARP_LDS_DMA
 #pragma unroll
     for (int i = 0; i < LDS_BYTES / 1024; ++i) {
         if (i < s.nld) {                                                     // wave-uniform
@@ -204,26 +193,6 @@ __device__ __forceinline__ void stage_dma(__amdgpu_buffer_rsrc_t rin, unsigned c
                                                      goff, 0, 0, 0);
         }
     }
-#else
-    auto goff_of = [&](int i) {
-        const unsigned q = (unsigned)(i * 64 + lane);
-        const unsigned r = (q * magic) >> 16;
-        const unsigned c = q - r * (unsigned)s.cpr;
-        return q < n ? base + r * (unsigned)rowBi + c * 16u : 0x80000000u;
-    };
-    int i = 0;
-    for (; i + 3 <= s.nld; i += 3) {                                       // wave-uniform trip counts
-        u32x4_t v[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, goff_of(i + u), 0, 0);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) *reinterpret_cast<u32x4_t*>(lds + (i + u) * 1024 + lane * 16) = v[u];
-    }
-    for (; i < s.nld; ++i) {
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rin, goff_of(i), 0, 0);
-        *reinterpret_cast<u32x4_t*>(lds + i * 1024 + lane * 16) = v;
-    }
-#endif
 }
 // the DMA's data is in LDS once the wave's vector-memory counter has drained; nothing else orders a ds_read behind it
 __device__ __forceinline__ void stage_wait() {
@@ -271,18 +240,12 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
     const int lane = threadIdx.x & 63, wave = wave_id();
     unsigned char* lds = lds_all + (STAGE_FWD ? wave * LDSW : 0);
     float cnt = 0.f;
-    // a block walks TPB_F consecutive virtual tiles (same image, neighbouring tiles: theta and the kernel arguments
-    // stay in SGPRs / the scalar cache, and the wave's start-up cost is paid once per TPB_F tiles)
-    const unsigned v0 = xcd_remap(blockIdx.x, gridDim.x) * TPB_F;
-#pragma unroll 1
-    for (int it = 0; it < TPB_F; ++it) {
-    const unsigned v = v0 + it;
-    if (v >= nblk) break;
+    const unsigned v = xcd_remap(blockIdx.x, nblk);
     const int b = v / tiles, tile = v - b * tiles;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int col = (tx * NWAVE + wave) * TW + (lane & (TW - 1));
     const int row0 = ty * TH + (lane / TW);                              // this lane's first row
-    if ((tx * NWAVE + wave) * TW >= ow) continue;                        // whole wave outside (wave-uniform)
+    if ((tx * NWAVE + wave) * TW >= ow) return;                          // whole wave outside (wave-uniform)
 #ifdef UH_WARP_TRACE
     unsigned long long* trp = (g_trace && lane == 0) ? g_trace + ((size_t)v * NWAVE + wave) * 8 : nullptr;
 #endif
@@ -428,11 +391,6 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // stores acknowledged
     UH_TR(7);
 #endif
-    if (TPB_F > 1) {                    // the next tile's DMA must not overtake this tile's LDS reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    }   // tiles of this block
     if (COND) {
         cnt = wave_sum(cnt);
         if (lane == 0) atomicAdd(condition, cnt);
@@ -643,53 +601,33 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                 }
             }
         } else {                                                        // ---- some tap is clipped
-            Stage st;
-            st.fits = false;
-            Extent ec;
-            // C1 costs the backward 27 VGPRs (123 vs 96: 4 instead of 5 waves per SIMD) and measured no faster than the
-            // gather there (profiles/r02_*), so clipped waves of the backward always gather unless UH_WARP_BWD_C1=1
-            if constexpr (STAGE_BWD && UH_WARP_BWD_C1) { ec = wave_extent_clipped_xy<STEPS_B>(p, g); st = plan_stage<C, LDSW>(ec); }
-#ifdef UH_WARP_NO_C1
-            st.fits = false;
-#endif
+            // (a staged clipped path like the forward's C1 cost the backward 27 VGPRs -- 4 instead of 5 waves per SIMD -- and
+            // measured no faster than the gather: profiles/r02_microbench_variants.jsonl, `noc1`)
             auto corners = [&](int k) {                                 // floor / clip of pixel k              (:101-109)
                 Coord c;
                 clip_pair(p[k].x, g.Wm1, c.x0f, c.x1f);
                 clip_pair(p[k].y, g.Hm1, c.y0f, c.y1f);
                 return c;
             };
-            if (STAGE_BWD && UH_WARP_BWD_C1 && st.fits) {               // ---- path C1: clipped rectangle through LDS
-                stage_dma<C, LDSW>(rin, lds, lane, ec, st, g.rowBi);
-                stage_wait();
+            // ---- path C2: clipped gather
 #pragma unroll
-                for (int k = 0; k < STEPS_B; ++k) {
-                    const Coord c = corners(k);
-                    const TapOff o = staged_offsets(c, st.pitch, g.pixB, st.nbase);
-                    const Pix<C> Ia = lds_load<C>(lds, o.oa), Ib = lds_load<C>(lds, o.ob);
-                    const Pix<C> Ic = lds_load<C>(lds, o.oc), Id = lds_load<C>(lds, o.od);
-                    accumulate(k, c.x1f - p[k].x, c.y1f - p[k].y, c.x1f - c.x0f, c.y1f - c.y0f, Ia, Ib, Ic, Id);
-                    __builtin_amdgcn_sched_barrier(0);                  // one pixel's taps live at a time (VGPR budget)
+            for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
+                Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];             // 4*BT_B gathers in flight
+                Coord c[BT_B];
+#pragma unroll
+                for (int j = 0; j < BT_B; ++j) {
+                    c[j] = corners(k0 + j);
+                    const TapOff o = global_offsets<SMALL>(c[j], g);
+                    Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
+                    Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
                 }
-            } else {                                                    // ---- path C2: clipped gather (far field)
 #pragma unroll
-                for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
-                    Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];             // 4*BT_B gathers in flight
-                    Coord c[BT_B];
-#pragma unroll
-                    for (int j = 0; j < BT_B; ++j) {
-                        c[j] = corners(k0 + j);
-                        const TapOff o = global_offsets<SMALL>(c[j], g);
-                        Ia[j] = buf_load<C>(rin, o.oa, 0); Ib[j] = buf_load<C>(rin, o.ob, 0);
-                        Ic[j] = buf_load<C>(rin, o.oc, 0); Id[j] = buf_load<C>(rin, o.od, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < BT_B; ++j) {
-                        const int k = k0 + j;
-                        accumulate(k, c[j].x1f - p[k].x, c[j].y1f - p[k].y, c[j].x1f - c[j].x0f, c[j].y1f - c[j].y0f,
-                                   Ia[j], Ib[j], Ic[j], Id[j]);
-                    }
-                    if (BT_B < STEPS_B) __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < BT_B; ++j) {
+                    const int k = k0 + j;
+                    accumulate(k, c[j].x1f - p[k].x, c[j].y1f - p[k].y, c[j].x1f - c[j].x0f, c[j].y1f - c[j].y0f,
+                               Ia[j], Ib[j], Ic[j], Id[j]);
                 }
+                if (BT_B < STEPS_B) __builtin_amdgcn_sched_barrier(0);
             }
             if (WANT_DU) {
 #pragma unroll
@@ -869,7 +807,7 @@ static void launch_fwd(const float* U, const float* theta, float* out, float* co
     const TileGeom g = tile_geom(oh, ow);
     const unsigned nblk = (unsigned)B * g.tiles;
     const bool sm = small_image(H, W, C);
-#define UH_FWD(COND, SM) launch_timed(UH_K_WARP_FWD, warp_forward_kernel<C, COND, SM>, dim3((nblk + TPB_F - 1) / TPB_F), dim3(256), s, U, \
+#define UH_FWD(COND, SM) launch_timed(UH_K_WARP_FWD, warp_forward_kernel<C, COND, SM>, dim3(nblk), dim3(256), s, U, \
                                      theta, out, condition, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk)
     if (condition) { if (sm) UH_FWD(true, true); else UH_FWD(true, false); }
     else           { if (sm) UH_FWD(false, true); else UH_FWD(false, false); }
