@@ -61,7 +61,7 @@ def parse():
                          '8(d)\'s mid-training law (perspective, clipped and far-field tiles) instead of the near-identity a '
                          '25-step-old regressor predicts; 0: the raw regressor')
     ap.add_argument('--cpu_sample_pairs', type=int, default=64, help='CPU leg: batch size (default = the GPU batch)')
-    ap.add_argument('--cpu_sample_steps', type=int, default=4, help='CPU leg: timed steps after one warm-up step')
+    ap.add_argument('--cpu_sample_steps', type=int, default=12, help='CPU leg: timed steps after one warm-up step')
     ap.add_argument('--cpu_threads', type=int, default=32, help='host threads for the CPU leg (capped at nproc)')
     return ap.parse_args()
 
@@ -281,6 +281,30 @@ def main():
         _, th_last = _ops.solve_dlt(batch['pts1'], model.pred_h4p.detach(), img_w=args.img_w, img_h=args.img_h)
         in_step_theta = {'law': 'regressor + gt + N(0,2px)' if args.mid_training_theta else 'raw regressor (near identity)',
                          'tile_paths': tile_paths(th_last, args.img_h, args.img_w)}
+    # the same in-step forward under the OTHER law, a few extra (untimed) steps after the timed region: lets a reader
+    # compare with round 1's line, whose timed steps ran the raw near-identity regressor
+    other_law = None
+    if args.profile and args.mid_training_theta and not args.step_graph and not args.fused_patch:
+        keep = step_fn.h4p_offset
+        step_fn.h4p_offset = None
+        for _ in range(2):
+            step_fn(batch)
+        torch.cuda.synchronize(device)
+        _lib.profile_enable(True, only=('warp_forward',))
+        for _ in range(8):
+            m2 = step_fn(batch)
+        torch.cuda.synchronize(device)
+        p2 = _lib.profile_read()
+        _lib.profile_enable(False)
+        step_fn.h4p_offset = keep
+        if p2['warp_forward'][1]:
+            us2 = p2['warp_forward'][0] / p2['warp_forward'][1] * 1e3
+            with torch.no_grad():
+                _, th2 = _ops.solve_dlt(batch['pts1'], m2.pred_h4p.detach(), img_w=args.img_w, img_h=args.img_h)
+            other_law = {'law': 'raw regressor (near identity), 8 untimed steps after the timed region',
+                         'warp_forward_avg_us': round(us2, 2),
+                         'frac': round(2 * B * args.img_h * args.img_w * 3 * 4 / (us2 * 1e-6) / HBM_PEAK, 4),
+                         'tile_paths': tile_paths(th2, args.img_h, args.img_w)}
     loss_val = float(model.loss.detach())
     h_loss_val = float(model.h_loss.detach())              # mean corner error (RMSE px) of the last batch: the net is 35 steps old
 
@@ -359,6 +383,8 @@ def main():
         'roofline': roofline,
     }
     out['config']['in_step_theta'] = in_step_theta
+    if other_law is not None and isinstance(out.get('roofline'), dict):
+        out['roofline']['same_kernel_under_round1_law'] = other_law
     if world > 1:
         out['config']['rccl_world_size'] = torch.distributed.get_world_size()
         out['config']['dist_backend'] = torch.distributed.get_backend()

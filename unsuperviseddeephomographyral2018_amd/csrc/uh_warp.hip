@@ -717,8 +717,18 @@ __global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* 
     if (b < B && lane < 63) {
         const float* p = partial + (size_t)b * tiles * 9;
         const int n = tiles * 9;
+        if constexpr (PATCH) {
+            // e advances by 63 = 7 tiles: walk (tx, ty) incrementally instead of dividing per element
+            int tile = lane / 9, ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
+            for (int e = lane; e < n; e += 63) {
+                if (tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi) a += (double)p[e];
+                tx += 7;
+                while (tx >= pf.tiles_x) { tx -= pf.tiles_x; ++ty; }
+            }
+        } else {
 #pragma unroll 4
-        for (int e = lane; e < n; e += 63) a += written(e / 9) ? (double)p[e] : 0.0;
+            for (int e = lane; e < n; e += 63) a += (double)p[e];
+        }
     }
     red[wave][lane] = a;
     double extra = 0.0;                                                  // lane j < 9: stray entries' share of sum j
