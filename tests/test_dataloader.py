@@ -120,3 +120,43 @@ def test_dataloader_end_to_end_from_disk(tmp_path, uh_lib_path):
                         b0['gt'], b0['patch_indices'])
     m.l1_loss.backward()
     assert torch.isfinite(m.l1_loss)
+
+
+@pytest.mark.gpu
+def test_dataloader_never_drops_pairs_and_never_spins(tmp_path, uh_lib_path):
+    """the loader dropped the remainder batch and an epoch over fewer pairs than batch_size yielded nothing, so
+    the trainer's `forever()` wrapper spun.  Now: stream() is an endless queue of FULL batches that cycles the list (the
+    reference's tf.train.batch queue never drops a sample either), __iter__ = ceil(n / B) batches, an empty list raises,
+    and test mode clamps the batch to the number of pairs like the reference (homography_CNN_synthetic.py:136)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    rs = np.random.RandomState(3)
+    N, H, W, P = 10, 48, 64, 16
+    I = _frames(rs, N, H, W); Ip = _frames(rs, N, H, W)
+    x0 = rs.randint(4, W - P - 4, N); y0 = rs.randint(4, H - P - 4, N)
+    pts1 = np.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).astype(np.float32)
+    gt = np.arange(N * 8).reshape(N, 8).astype(np.float32)               # row k identifies pair k
+    ff, fp, fg = dl.write_dataset(str(tmp_path) + '/', I, Ip, pts1, gt)
+    mk = lambda B: dl.dataloader_params(data_path=str(tmp_path) + '/', filenames_file=ff, pts1_file=fp, gt_file=fg, mode='test',
+                                        batch_size=B, img_h=H, img_w=W, patch_size=P, augment_list=['normalize'], do_augment=0.0)
+    loader = dl.Dataloader(mk(4), shuffle=False)
+    assert len(loader) == 3
+    ids = [b['gt'][:, 0].cpu().numpy() / 8 for b in loader]
+    assert [list(map(int, i)) for i in ids] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 0, 1]]          # tail completed by wrapping
+    seen = set()
+    it = loader.stream()
+    for _ in range(5):
+        seen.update(int(v) for v in next(it)['gt'][:, 0].cpu().numpy() / 8)
+    assert seen == set(range(N))                                                                      # every pair delivered
+    big = dl.Dataloader(mk(16), shuffle=True)                                                        # fewer pairs than a batch
+    b = next(big.stream())
+    assert b['gt'].shape[0] == 16 and len(set(map(int, b['gt'][:, 0].cpu().numpy() / 8))) == N
+    assert len(list(big)) == 1
+    open(ff, 'w').close(); open(fp, 'w').close(); open(fg, 'w').close()
+    try:
+        empty = dl.Dataloader(mk(4), shuffle=False)
+        with pytest.raises(ValueError):
+            next(empty.stream())
+    except ValueError:
+        pass                                                                                          # raising at construction is fine too
