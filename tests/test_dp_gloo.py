@@ -54,9 +54,9 @@ def _worker(rank, world, port, q, backend='gloo'):
         avg.finish()
         res.append([p.grad.clone() for p in net.parameters()])
     vals = D.all_reduce_mean_scalars([loss], world)
-    if backend == 'nccl':
-        tb = avg.time_buckets(iters=2)
-        assert len(tb) == 2 and all(b['ms'] > 0 for b in tb)
+    tb = avg.time_buckets(iters=2)                 # the stand-alone exchange timing bench.py --gpus N reports
+    assert len(tb) == 2 and all(b['ms'] > 0 and b['bytes'] > 0 for b in tb)
+    assert avg.finishes == 2 and avg.exposed_wait_s >= 0.0
     q.put((rank, [[t.cpu().numpy() for t in r_] for r_ in res], float(vals[0])))
     torch.distributed.destroy_process_group()
 

@@ -9,6 +9,9 @@ timeout 300 python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1
 timeout 900 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
 timeout 400 python bench.py --cpu_baseline 0 --north_star 0 --config4 0 --fused_patch 1 > gpurun_out/${TAG}_bench_line_fused_patch.json 2>/dev/null
 timeout 400 python bench.py --cpu_baseline 0 --north_star 0 --config4 0 --mid_training_theta 0 > gpurun_out/${TAG}_bench_line_raw_regressor.json 2>/dev/null
+# functional check of the N > 1 path of bench.py on a 1-GPU box: 2 ranks share the GPU over gloo (RCCL needs a device per rank)
+UH_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+    bench.py --gpus 2 --steps 5 --warmup 2 --cpu_baseline 0 > gpurun_out/${TAG}_bench_line_2ranks_gloo_one_gpu.json 2> gpurun_out/${TAG}_bench_2ranks.err
 CMD="python /root/repo/bench.py --steps 30 --warmup 5 --cpu_baseline 0 --north_star 0 --config4 0"
 ( cd /tmp && rm -rf /tmp/prof_$TAG && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench --output-format csv -- $CMD > /root/repo/gpurun_out/${TAG}_bench_line_under_rocprof.json 2>/dev/null )
 cp $(find /tmp/prof_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_bench_kernel_stats.csv 2>/dev/null

@@ -17,7 +17,7 @@ struct uh_tail_plan {
     int B, H, W, C, P;
     unsigned flags;
     // workspace layout (byte offsets, 256-byte aligned)
-    size_t off_theta, off_dtheta, off_warped, off_dwarped, off_dpred, off_ws_warp, off_ws_l1, off_ws_patch, off_one, total;
+    size_t off_theta, off_dtheta, off_warped, off_dpred, off_ws_warp, off_ws_l1, off_ws_patch, off_one, total;
     // A captured graph bakes in every kernel ARGUMENT: the pointers and the M / Minv constants (passed by value to the
     // DLT kernels).  The key therefore holds both; a caller that re-runs a plan with different M_host contents gets a
     // fresh capture, never stale constants.
@@ -45,7 +45,7 @@ extern "C" int uh_tail_create(uh_tail_plan** out, int B, int H, int W, int C, in
     p->off_dtheta = o;  o = align256(o + (size_t)B * 9 * sizeof(float));
     p->off_one = o;     o = align256(o + sizeof(float));
     p->off_warped = o;  o = align256(o + (fused ? 0 : frame));
-    p->off_dwarped = o;                      // (no dWarped frame any more: the backward takes dPred directly)
+    // (no dWarped frame: the backward takes dPred directly -- uh_warp_patch_backward)
     p->off_dpred = o;   o = align256(o + (fused ? 0 : patch));
     p->off_ws_warp = o; o = align256(o + (fused ? 0 : uh_warp_patch_backward_workspace_bytes(B, H, W, C)));
     p->off_ws_l1 = o;   o = align256(o + (fused ? 0 : uh_l1_loss_workspace_bytes((size_t)B * P * P)));

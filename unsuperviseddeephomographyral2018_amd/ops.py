@@ -434,7 +434,7 @@ def warp_patch_l1(U, theta, I2, patch_indices, patch_size):
 # ------------------------------------------------------------------------------------------------
 class TailPlan(object):
     """uh_tail_plan + its persistent workspace for one shape.  Keeping the workspace (and
-    therefore theta / warped / dWarped ...) at fixed addresses is what lets the captured hipGraph be replayed."""
+    therefore theta / warped / dPred ...) at fixed addresses is what lets the captured hipGraph be replayed."""
     _cache = {}
 
     def __init__(self, B, H, W, Cc, P, device, fused_patch=False, graph=True, solve_f64=False):
