@@ -130,7 +130,7 @@ def tile_paths(theta, H, W, lds_bytes=6144, tile=16):
     def fits(x0, x1, y0, y1):
         rw, rh = x1 - x0 + 1, y1 - y0 + 1
         cpr = torch.ceil(rw * 12 / 16)
-        return (cpr <= 64) & (torch.ceil(cpr * rh / 64) * 1024 <= lds_bytes)
+        return (cpr <= 64) & (cpr * rh * 16 <= lds_bytes)
     fitA = fits(mn(fx), mx(fx) + 1, mn(fy), mx(fy) + 1)
     cx0, cx1 = fx.clamp(0, W - 1), (fx + 1).clamp(0, W - 1)
     cy0, cy1 = fy.clamp(0, H - 1), (fy + 1).clamp(0, H - 1)

@@ -158,41 +158,44 @@ __device__ __forceinline__ Extent wave_extent_clipped_xy(const Proj (&p)[N], con
 }
 
 // ---- path A staging: LDS-DMA of the tap rectangle ------------------------------------------------------------
-// The rectangle's rows are cut into 16-byte chunks, cpr = ceil(rw*C*4/16) per row, and chunk q = r*cpr + c goes to
-// LDS byte 16*q: one buffer_load_dwordx4 ... lds moves 64 consecutive chunks (1 KiB) straight into the slice (the
-// LDS address of lane l is M0 + imm + 16*l by construction of the instruction), so rows are PACKED at pitch 16*cpr
-// and a slice of S bytes holds any rectangle with ceil(rh*cpr/64) KiB <= S.  The global address of a chunk,
-// ((by0+r)*W + bx0)*C*4 + 16*c, is only 4-byte aligned; the last chunk of a row may run past the rectangle (never
-// read).  q -> (r, c) by a multiply-shift (exact for q*cpr < 2^16: q < 1024, cpr <= 64).
-struct Stage { int cpr, nld; float pitch, nbase; bool fits; };
+// The rectangle's rows are cut into 16-byte chunks, cpr = ceil(rw*C*4/16) per row, packed in LDS at pitch 16*cpr.  One
+// buffer_load_dwordx4 ... lds moves rpi = floor(64/cpr) WHOLE rows (the LDS address of lane l is M0 + 16*l by
+// construction of the instruction, so lane l = r*cpr + c lands on row r, chunk c of the instruction's block of rows):
+// the lane's (r, c) and its global offset are computed ONCE, every further instruction only moves two scalars (M0 by
+// rpi rows of LDS, the buffer instruction's soffset by rpi rows of the image) and lanes past the last row are masked.
+// The global address of a chunk, ((by0+r)*W + bx0)*C*4 + 16*c, is only 4-byte aligned; the last chunk of a row may
+// run past the rectangle (never read).  The rectangle lies inside the image on both staged paths, so no range check
+// is involved.  A slice of S bytes holds any rectangle with rh*cpr*16 <= S.
+struct Stage { int cpr, rpi, nld; float pitch, nbase; bool fits; };
 template <int C, int LDS_BYTES>
 __device__ __forceinline__ Stage plan_stage(const Extent& e) {
     Stage s;
     s.cpr = (e.rw * C * 4 + 15) >> 4;
-    const int n = s.cpr * e.rh;
-    s.nld = (n + 63) >> 6;
-    s.fits = e.interior && s.cpr <= 64 && s.nld * 1024 <= LDS_BYTES;
+    s.fits = e.interior && s.cpr <= 64 && s.cpr * e.rh * 16 <= LDS_BYTES;
+    s.rpi = 64 / max(s.cpr, 1);                      // wave-uniform operands: the quotient lives in an SGPR (the loop
+                                                     // below must step scalars, or the compiler "waterfalls" the DMA)
+    s.nld = 0;
     s.pitch = (float)(s.cpr * 16);
     s.nbase = -((float)e.by0 * s.pitch + (float)(e.bx0 * C * 4));
     return s;
 }
 template <int C, int LDS_BYTES>
 __device__ __forceinline__ void stage_dma(__amdgpu_buffer_rsrc_t rin, unsigned char* lds, int lane, const Extent& e,
-                                          const Stage& s, int rowBi) {
-    const unsigned magic = (65536u + (unsigned)s.cpr - 1u) / (unsigned)s.cpr;     // wave-uniform (SALU)
-    const unsigned n = (unsigned)(s.cpr * e.rh);
-    const unsigned base = (unsigned)e.by0 * (unsigned)rowBi + (unsigned)(e.bx0 * C * 4);
-#pragma unroll
-    for (int i = 0; i < LDS_BYTES / 1024; ++i) {
-        if (i < s.nld) {                                                     // wave-uniform
-            const unsigned q = (unsigned)(i * 64 + lane);
-            const unsigned r = (q * magic) >> 16;
-            const unsigned c = q - r * (unsigned)s.cpr;
-            const unsigned goff = q < n ? base + r * (unsigned)rowBi + c * 16u : 0x80000000u;   // out of range -> zeros
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
-                                                     goff, 0, 0, 0);
-        }
+                                          Stage& s, int rowBi) {
+    // lane -> (row r, chunk c) of one instruction's block of rows:  r = floor((lane + 0.5) / cpr)  (off integers by >= 1/128)
+    const int r = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)s.cpr));
+    const int c = lane - r * s.cpr;
+    const unsigned goff = (unsigned)(e.by0 + r) * (unsigned)rowBi + (unsigned)(e.bx0 * C * 4 + c * 16);
+    const int rpi = s.rpi;
+    const unsigned gstep = (unsigned)rpi * (unsigned)rowBi, lstep = (unsigned)(rpi * s.cpr * 16);
+    int n = 0;
+#pragma unroll 1
+    for (int row = 0; row < e.rh; row += rpi, ++n) {                      // wave-uniform trip count (<= LDS_BYTES / 528)
+        if (r < min(rpi, e.rh - row))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(lds + (unsigned)n * lstep), 16,
+                                                     goff, (int)((unsigned)n * gstep), 0, 0);
     }
+    s.nld = n;
 }
 // the DMA's data is in LDS once the wave's vector-memory counter has drained; nothing else orders a ds_read behind it
 __device__ __forceinline__ void stage_wait() {
@@ -529,9 +532,10 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
             const float rt = p[k].rt;
             const float dxs = dx * halfW * rt, dys = dy * halfH * rt;
             const float dt = -(dxs * p[k].xs + dys * p[k].ys) * rt;
-            acc[0] = fmaf(dxs, gx, acc[0]); acc[1] = fmaf(dxs, gy[k], acc[1]); acc[2] += dxs;
-            acc[3] = fmaf(dys, gx, acc[3]); acc[4] = fmaf(dys, gy[k], acc[4]); acc[5] += dys;
-            acc[6] = fmaf(dt,  gx, acc[6]); acc[7] = fmaf(dt,  gy[k], acc[7]); acc[8] += dt;
+            // gx is the same for the lane's four pixels (one column): the gx-weighted sums are formed once, after the loop
+            acc[1] = fmaf(dxs, gy[k], acc[1]); acc[2] += dxs;
+            acc[4] = fmaf(dys, gy[k], acc[4]); acc[5] += dys;
+            acc[7] = fmaf(dt,  gy[k], acc[7]); acc[8] += dt;
         };
         // optional dU: scatter of the four weighted taps (the only float atomics of the library).  A sample whose x (or y)
         // pair collapsed under the clip sends wa + wc = (ax1 + ax0) ay1 = 0 to ONE pixel: in exact arithmetic it
@@ -552,12 +556,10 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
             st.fits = false;
             if constexpr (STAGE_BWD) st = plan_stage<C, LDSW>(e);
             float ax0[STEPS_B], ay0[STEPS_B];
-            unsigned og[STEPS_B];                                       // global offset of tap (y0, x0)
-#pragma unroll
-            for (int k = 0; k < STEPS_B; ++k) {
-                if constexpr (SMALL) og[k] = (unsigned)__builtin_fmaf(fy[k], g.rowB, fx[k] * g.pixB);
-                else og[k] = (unsigned)fy[k] * (unsigned)g.rowBi + (unsigned)fx[k] * (unsigned)g.pixBi;
-            }
+            auto og = [&](int k) -> unsigned {                          // global offset of tap (y0, x0): paths B and dU only
+                if constexpr (SMALL) return (unsigned)__builtin_fmaf(fy[k], g.rowB, fx[k] * g.pixB);
+                else return (unsigned)fy[k] * (unsigned)g.rowBi + (unsigned)fx[k] * (unsigned)g.pixBi;
+            };
             if (STAGE_BWD && st.fits) {                                 // ---- path A
                 stage_dma<C, LDSW>(rin, lds, lane, e, st, g.rowBi);
                 unsigned oa[STEPS_B];
@@ -581,7 +583,8 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
 #pragma unroll
                     for (int j = 0; j < BT_B; ++j) {
                         const int k = k0 + j;
-                        global_quad<C>(rin, og[k], og[k] + (unsigned)g.rowBi, Ia[j], Ib[j], Ic[j], Id[j]);
+                        const unsigned o = og(k);
+                        global_quad<C>(rin, o, o + (unsigned)g.rowBi, Ia[j], Ib[j], Ic[j], Id[j]);
                         ax0[k] = p[k].x - fx[k]; ay0[k] = p[k].y - fy[k];
                     }
 #pragma unroll
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
 #pragma unroll
                 for (int k = 0; k < STEPS_B; ++k) {
                     TapOff o;
-                    o.oa = og[k]; o.ob = og[k] + (unsigned)g.rowBi; o.oc = o.oa + C * 4; o.od = o.ob + C * 4;
+                    o.oa = og(k); o.ob = o.oa + (unsigned)g.rowBi; o.oc = o.oa + C * 4; o.od = o.ob + C * 4;
                     scatter(k, o, 1.0f - ax0[k], ax0[k], 1.0f - ay0[k], ay0[k], true);
                 }
             }
@@ -638,6 +641,7 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                 }
             }
         }
+        acc[0] = gx * acc[2]; acc[3] = gx * acc[5]; acc[6] = gx * acc[8];
     }
     // block reduction: DPP inside rows of 16 lanes, the 16 row sums of the block meet in LDS (fixed order)
 #pragma unroll
