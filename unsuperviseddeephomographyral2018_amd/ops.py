@@ -7,6 +7,10 @@ tensors raises -- there is no CPU fallback.
 Mirrors, by name and argument meaning:
   transformer(U, theta, out_size)       /root/reference/code/utils/tf_spatial_transformer.py:18
   solve_dlt(pts1, h4p)                  /root/reference/code/homography_model.py:169-250
+  warp_gather(U, theta, idx, P)         transform(), homography_model.py:257-269 (full-frame warp + gray gather, sparse backward)
+  warp_patch / warp_patch_l1            the same restricted to the loss patch (no warped frame)
+  patch_losses(pred, I2, h4p, gt, train)  build_losses(), homography_model.py:286-352 (six values, HIP gradient of the trained one)
+  photometric_tail(...)                 solve_DLT + transform + l1 loss and their backward as one library call / hipGraph
 """
 import ctypes as C
 
