@@ -65,6 +65,11 @@ extern "C" {
 /* flags for uh_dlt_* */
 #define UH_DLT_SOLVE_F32   0u   /* default: f32 partial-pivot LU, the tf.matrix_solve semantics  */
 #define UH_DLT_SOLVE_F64   1u   /* same algorithm carried in f64, result rounded to f32           */
+#define UH_DLT_ZERO_NONFINITE_GRAD 8u   /* uh_dlt_backward: a system whose dh4p has a NaN / Inf entry gets dh4p = 0 for all 8.
+                                         * Not reference behaviour (tf.matrix_solve raises on a singular system and lets NaN
+                                         * through otherwise): the trainer sets it so that ONE pair whose predicted corners are
+                                         * degenerate (collinear p2, theta = NaN) contributes no gradient instead of turning every
+                                         * variable into NaN -- observed once in 5.4 M pairs (profiles/r02_train_long_*).        */
 
 typedef void* uh_stream_t;     /* hipStream_t */
 
@@ -194,7 +199,7 @@ UH_API int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const flo
 #define UH_TAIL_FUSED_PATCH  2u   /* use uh_warp_patch_l1_fwdbwd instead of the full-frame warp (no `warped`)      */
 #define UH_TAIL_GRAPH        4u   /* replay a captured hipGraph                                                     */
 typedef struct uh_tail_plan uh_tail_plan;
-UH_API int    uh_tail_create(uh_tail_plan** plan, int B, int H, int W, int C, int P, unsigned flags /* | UH_DLT_SOLVE_F64 */);
+UH_API int    uh_tail_create(uh_tail_plan** plan, int B, int H, int W, int C, int P, unsigned flags /* | UH_DLT_SOLVE_F64 | UH_DLT_ZERO_NONFINITE_GRAD */);
 UH_API size_t uh_tail_workspace_bytes(const uh_tail_plan* plan);
 UH_API size_t uh_tail_warped_offset(const uh_tail_plan* plan);   /* byte offset of `warped` [B,H,W,C] in the workspace; (size_t)-1 when fused */
 UH_API int    uh_tail_run(uh_tail_plan* plan, const float* pts1, const float* h4p, const float* U, const float* I2,

@@ -303,6 +303,50 @@ def test_tail_plan_reentry_constants_and_address_churn(pkg, dev):
         assert plan.stats()['captures'] - c0 <= 9, plan.stats()
 
 
+@pytest.mark.parametrize('kind', ['collapsed', 'overflow'])
+def test_degenerate_pair_does_not_poison_the_variables(pkg, dev, kind):
+    """A 100 000-step run died at ~85 k steps: ONE pair with a degenerate corner prediction gave a non-finite theta, and
+    NaN flowed through d loss / d pred_h4p into every variable (profiles/r02_train_long_100k_nan_at_85k.txt).  In train
+    mode the DLT backward now zeroes the gradient of such a pair (UH_DLT_ZERO_NONFINITE_GRAD): the other pairs' gradients
+    are untouched, the variables' gradients stay finite.  With the guard off the NaN is passed on, as the reference does."""
+    hm, synthetic, _ = pkg
+    from unsuperviseddeephomographyral2018_amd import ops
+    batch = synthetic.make_batch(B, H, W, P, RHO, seed=31, device=dev)
+    good = torch.randn(B, 8, device=dev) * 3
+    bad = good.clone()
+    if kind == 'collapsed':
+        bad[1] = torch.tensor([100., 100.] * 4, device=dev) - batch['pts1'][1]      # all four p2 corners on one point
+    else:
+        bad[1] = 1e30                                                               # products overflow -> inf - inf
+    grads = {}
+    for name, h4p0, guard in (('good', good, True), ('bad_guarded', bad, True), ('bad_raw', bad, False)):
+        h = h4p0.clone().requires_grad_(True)
+        _, theta = ops.solve_dlt(batch['pts1'], h, W, H, zero_nonfinite_grad=guard)
+        _, pred = ops.warp_gather(batch['I_aug'], theta, batch['patch_indices'], P)
+        loss = ops.patch_losses(pred, batch['I2_aug'], train='l1_loss')[2]
+        loss.backward()
+        grads[name] = h.grad.clone()
+    assert torch.isfinite(grads['bad_guarded']).all()
+    keep = [0, 2, 3]
+    assert torch.equal(grads['bad_guarded'][keep], grads['good'][keep])             # the other pairs are untouched
+    if not torch.isfinite(grads['bad_raw'][1]).all():                               # the guard fired for pair 1
+        assert float(grads['bad_guarded'][1].abs().max()) == 0.0
+    if kind == 'overflow':
+        assert not torch.isfinite(grads['bad_raw'][1]).all()                        # guard off: NaN goes on to the regressor
+    # the model switches the guard on in train mode: a full step leaves every variable gradient finite
+    torch.manual_seed(0)
+    net = hm.VGGRegressor(P).to(dev).to(memory_format=torch.channels_last).eval()   # (no dropout: pred_h4p == bad exactly)
+    with torch.no_grad():
+        offset = bad - net(torch.cat([batch['I1_aug'], batch['I2_aug']], 3))
+    for graph_tail in (False, True):
+        net.zero_grad(set_to_none=True)
+        m = hm.HomographyModel(params(hm, 'train', B, P, W, H, 'l1_loss'), *synthetic.model_args(batch), net=net,
+                               h4p_offset=offset, graph_tail=graph_tail)
+        assert m.zero_nonfinite_grad
+        m.loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters()), graph_tail
+
+
 def test_conv_bias_relu_epilogue_equals_torch(pkg, dev):
     """ops.conv_bias_relu (MIOpen conv + HIP bias/ReLU epilogue) vs F.relu(F.conv2d(x, w, b)): same forward bits,
     gradients within f32 reduction-order noise; and the whole regressor with / without the fused epilogue."""

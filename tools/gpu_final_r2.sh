@@ -23,4 +23,6 @@ for W in bench c4; do
   ( cd /tmp && rm -rf /tmp/pmc_$W && mkdir -p /tmp/pmc_$W && i=0 && for C in "FETCH_SIZE" "WRITE_SIZE"; do i=$((i+1)); timeout 400 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$W/p$i -o p --output-format csv -- $PC > /tmp/pmc_$W/log$i.txt 2>&1 || echo "pmc pass $W $i failed"; done )
   python tools/traffic_from_pmc.py /tmp/pmc_$W $DIMS gpurun_out/traffic_${TAG}.json "$PC" "measured $(date -u +%Y-%m-%d) on one MI355X at commit $COMMIT by tools/gpu_final_r2.sh" > /dev/null
 done
+# SQ / TCP / TD / TCC counters of the warp kernels at config 4 (one counter group per pass, --kernel-trace only)
+bash tools/gpu_pmc2.sh 128,480,640,128,64 ${TAG}_c4 > gpurun_out/${TAG}_pmc.log 2>&1
 echo done

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hot
 UH_ABI_VERSION = 2
 UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
+UH_DLT_ZERO_NONFINITE_GRAD = 8
 UH_TAIL_FUSED_PATCH = 2
 UH_TAIL_GRAPH = 4
 LOSS_KINDS = {'rec_loss': 0, 'ssim_loss': 1, 'l1_loss': 2, 'l1_smooth_loss': 3, 'ncc_loss': 4}

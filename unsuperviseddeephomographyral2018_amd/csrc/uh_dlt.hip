@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void dlt_backward_kernel(const float* __restri
                                                            const float* __restrict__ dH,
                                                            const float* __restrict__ dtheta,
                                                            Mat3 MT, Mat3 MinvT,
-                                                           float* __restrict__ dh4p, int B) {
+                                                           float* __restrict__ dh4p, int B, int zero_nonfinite) {
     const int sys = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sys >= B) return;
     const int lane = threadIdx.x & 63;
@@ -159,8 +159,12 @@ __global__ __launch_bounds__(256) void dlt_backward_kernel(const float* __restri
         T gb_odd = 0, gb_even = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (i == j) { gb_even = x[2 * j]; gb_odd = x[2 * j + 1]; }
-        const T v = (lane & 1) ? -gb_even * s : gb_odd * s;
-        dh4p[(size_t)sys * 8 + lane] = (float)v;
+        float v = (float)((lane & 1) ? -gb_even * s : gb_odd * s);
+        if (zero_nonfinite) {                               // UH_DLT_ZERO_NONFINITE_GRAD: all 8 or nothing
+            const bool bad = !(fabsf(v) <= 3.402823466e38f);          // NaN or Inf
+            if (__ballot(bad) != 0ull) v = 0.f;                       // (only lanes 0..7 are active here)
+        }
+        dh4p[(size_t)sys * 8 + lane] = v;
     }
 }
 
@@ -203,10 +207,11 @@ extern "C" int uh_dlt_backward(const float* pts1, const float* h4p, const float*
     Mat3 MT = load_mat3(M_host, true), MinvT = load_mat3(Minv_host, true);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((B + 3) / 4), block(256);
+    const int zn = (flags & UH_DLT_ZERO_NONFINITE_GRAD) ? 1 : 0;
     ProfScope prof(UH_K_DLT_BWD, s);
     if (flags & UH_DLT_SOLVE_F64)
-        hipLaunchKernelGGL(dlt_backward_kernel<double>, grid, block, 0, s, pts1, h4p, H, dH, dtheta, MT, MinvT, dh4p, B);
+        hipLaunchKernelGGL(dlt_backward_kernel<double>, grid, block, 0, s, pts1, h4p, H, dH, dtheta, MT, MinvT, dh4p, B, zn);
     else
-        hipLaunchKernelGGL(dlt_backward_kernel<float>, grid, block, 0, s, pts1, h4p, H, dH, dtheta, MT, MinvT, dh4p, B);
+        hipLaunchKernelGGL(dlt_backward_kernel<float>, grid, block, 0, s, pts1, h4p, H, dH, dtheta, MT, MinvT, dh4p, B, zn);
     return (int)hipGetLastError();
 }

@@ -145,15 +145,23 @@ __global__ __launch_bounds__(256) void patch_loss_backward_kernel(const float* _
     } else {
         c2 = g * inv_n;
     }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float x = X[i], y = Y[i], d = x - y;
-        float r;
-        if (KIND == UH_LOSS_REC) r = c0 * d;
-        else if (KIND == UH_LOSS_NCC) r = c0 * y + c1 * x;
-        else if (KIND == UH_LOSS_L1) r = d > 0.f ? c2 : (d < 0.f ? -c2 : 0.f);
-        else r = fabsf(d) < 1.0f ? c2 * d : (d > 0.f ? c2 : -c2);
-        dX[i] = r;
+    auto grad = [&](float x, float y) {
+        const float d = x - y;
+        if (KIND == UH_LOSS_REC) return c0 * d;
+        if (KIND == UH_LOSS_NCC) return c0 * y + c1 * x;
+        if (KIND == UH_LOSS_L1) return d > 0.f ? c2 : (d < 0.f ? -c2 : 0.f);
+        return fabsf(d) < 1.0f ? c2 * d : (d > 0.f ? c2 : -c2);
+    };
+    // 16 bytes per lane (the patch tensors are 16-byte aligned whenever P*P % 4 == 0; hipMalloc / torch allocations are)
+    const size_t n4 = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dX)) & 15) ? 0 : n / 4;
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    const float4* Y4 = reinterpret_cast<const float4*>(Y);
+    float4* D4 = reinterpret_cast<float4*>(dX);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 x = X4[i], y = Y4[i];
+        D4[i] = make_float4(grad(x.x, y.x), grad(x.y, y.y), grad(x.z, y.z), grad(x.w, y.w));
     }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dX[i] = grad(X[i], Y[i]);
 }
 
 // SSIM: loss = (1/Ns) sum_w clip((1 - SSIM_w)/2, 0, 1) over the VALID 3x3 windows w.  With the window sums,
@@ -242,7 +250,8 @@ extern "C" int uh_patch_loss_backward(int kind, const float* pred, const float* 
     if ((uint64_t)B * P * P >= (1ull << 31)) return UH_E_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * P * P;
-    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    const size_t nt = (n + 3) / 4;                                     // threads needed at 4 elements each
+    const unsigned grid = (unsigned)((nt + 255) / 256 < 2048 ? (nt + 255) / 256 : 2048);
     switch (kind) {
         case UH_LOSS_REC: launch_timed(UH_K_LOSS_BWD, patch_loss_backward_kernel<UH_LOSS_REC>, dim3(grid), dim3(256), s, pred, target, stats16, dLoss, dPred, n); break;
         case UH_LOSS_L1: launch_timed(UH_K_LOSS_BWD, patch_loss_backward_kernel<UH_LOSS_L1>, dim3(grid), dim3(256), s, pred, target, stats16, dLoss, dPred, n); break;

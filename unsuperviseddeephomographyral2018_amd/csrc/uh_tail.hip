@@ -78,7 +78,7 @@ static int enqueue_chain(const uh_tail_plan* p, const float* pts1, const float* 
                          const int* idx, const float* M, const float* Minv, float* Hm, float* pred, float* loss,
                          float* dh4p, unsigned char* ws, hipStream_t s) {
     const int B = p->B, H = p->H, W = p->W, C = p->C, P = p->P, PP = P * P;
-    const unsigned dflags = p->flags & UH_DLT_SOLVE_F64;
+    const unsigned dflags = p->flags & (UH_DLT_SOLVE_F64 | UH_DLT_ZERO_NONFINITE_GRAD);
     float* theta = (float*)(ws + p->off_theta);
     float* dtheta = (float*)(ws + p->off_dtheta);
     int e;

@@ -293,6 +293,7 @@ def train(args):
         pool_gen = torch.Generator().manual_seed(args.seed * 7919 + rank)
     window = torch.zeros(len(names), device=device)
     win_n = 0
+    nonfinite_steps = torch.zeros((), device=device)
     t0 = time.time()
     for step in range(start_step, start_step + args.num_total_steps):
         if disk is not None:
@@ -308,6 +309,9 @@ def train(args):
         model = step_fn(batch)
         vals = uh_dist.all_reduce_mean_scalars([getattr(model, n) for n in names], world)
         cur = torch.stack([v.detach() for v in vals])
+        finite = torch.isfinite(cur)
+        nonfinite_steps += (~finite.all()).float()          # a degenerate pair makes that step's loss VALUE NaN (its gradient is
+        cur = torch.where(finite, cur, torch.zeros_like(cur))   # zeroed in the DLT backward): keep it out of the running means
         totals += cur
         window += cur
         win_n += 1
@@ -318,7 +322,8 @@ def train(args):
             dt = time.time() - t0
             print('Train: step %d  ' % step + ', '.join('%s %.6f' % (k, v) for k, v in zip(names, avg))
                   + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
-                  + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)]),
+                  + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)])
+                  + ('  | %d steps with a non-finite loss value so far' % int(nonfinite_steps) if float(nonfinite_steps) else ''),
                   flush=True)
             window.zero_(); win_n = 0
         if rank == 0 and step and step % args.save_every == 0:

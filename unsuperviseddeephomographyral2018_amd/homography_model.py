@@ -121,7 +121,7 @@ def reset_variables():
 class HomographyModel(object):
     def __init__(self, args, I1, I2, I1_aug, I2_aug, I_aug, I_prime_aug, h4p, gt, patch_indices,
                  reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False, graph_tail=False,
-                 h4p_offset=None):
+                 h4p_offset=None, zero_nonfinite_grad=None):
         self.params = args
         self.mode = args.mode
         self.is_training = True if self.mode == 'train' else False
@@ -142,6 +142,10 @@ class HomographyModel(object):
         self.fused_patch = fused_patch
         self.solve_f64 = solve_f64
         self.h4p_offset = h4p_offset        # [B,8] added to the regressor's output (bench / test hook; None = off)
+        # A pair whose predicted corners are degenerate (collinear p2 -> singular 8x8 system -> theta = NaN) must not turn
+        # every variable into NaN: in training its d loss / d pred_h4p is zeroed (UH_DLT_ZERO_NONFINITE_GRAD).  The reference
+        # has no such guard (tf.matrix_solve raises on a singular system); default = on in train mode.
+        self.zero_nonfinite_grad = (args.mode == 'train') if zero_nonfinite_grad is None else bool(zero_nonfinite_grad)
         # one library call / one hipGraph launch for solve_DLT + transform + l1 loss and their backward (l1_loss only)
         self.graph_tail = bool(graph_tail) and args.loss_type == 'l1_loss'
         if args.loss_type not in LOSS_TYPES:
@@ -189,12 +193,13 @@ class HomographyModel(object):
             with torch.set_grad_enabled(self._hot_grad):
                 self._tail = ops.photometric_tail(self.pts_1, self.pred_h4p, self.I, self.I2_aug, self.patch_indices,
                                                   self.params.patch_size, fused_patch=self.fused_patch, graph=True,
-                                                  solve_f64=self.solve_f64)
+                                                  solve_f64=self.solve_f64, zero_nonfinite_grad=self.zero_nonfinite_grad)
             self.H_mat = self._tail[2]
             return
         with torch.set_grad_enabled(self._hot_grad):
             self.H_mat, self._theta = ops.solve_dlt(self.pts_1, self.pred_h4p, self.params.img_w,
-                                                    self.params.img_h, solve_f64=self.solve_f64)
+                                                    self.params.img_h, solve_f64=self.solve_f64,
+                                                    zero_nonfinite_grad=self.zero_nonfinite_grad)
 
     # ---- homography_model.py:252-269 ----------------------------------------------------------------
     def transform(self):

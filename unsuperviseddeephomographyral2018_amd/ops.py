@@ -107,9 +107,11 @@ class _DLTSolve(torch.autograd.Function):
         return None, dh4p, None, None, None
 
 
-def solve_dlt(pts1, h4p, img_w=None, img_h=None, solve_f64=False):
+def solve_dlt(pts1, h4p, img_w=None, img_h=None, solve_f64=False, zero_nonfinite_grad=False):
     """Tensor-DLT.  Returns H [B,3,3]; with img_w/img_h also theta = M^-1 H M (transform() :254)."""
     flags = _lib.UH_DLT_SOLVE_F64 if solve_f64 else _lib.UH_DLT_SOLVE_F32
+    if zero_nonfinite_grad:          # a pair with degenerate predicted corners contributes no gradient (see the header)
+        flags |= _lib.UH_DLT_ZERO_NONFINITE_GRAD
     if img_w is None:
         return _DLTSolve.apply(pts1, h4p, None, None, flags)
     M, Minv = m_and_minv(img_w, img_h)
@@ -441,12 +443,12 @@ class TailPlan(object):
     therefore theta / warped / dPred ...) at fixed addresses is what lets the captured hipGraph be replayed."""
     _cache = {}
 
-    def __init__(self, B, H, W, Cc, P, device, fused_patch=False, graph=True, solve_f64=False):
+    def __init__(self, B, H, W, Cc, P, device, fused_patch=False, graph=True, solve_f64=False, zero_nonfinite_grad=False):
         lib = _lib.load()
         self.dims = (B, H, W, Cc, P)
         self.fused = bool(fused_patch)
         flags = (_lib.UH_TAIL_FUSED_PATCH if fused_patch else 0) | (_lib.UH_TAIL_GRAPH if graph else 0) \
-            | (_lib.UH_DLT_SOLVE_F64 if solve_f64 else 0)
+            | (_lib.UH_DLT_SOLVE_F64 if solve_f64 else 0) | (_lib.UH_DLT_ZERO_NONFINITE_GRAD if zero_nonfinite_grad else 0)
         h = C.c_void_p()
         _lib.check(lib.uh_tail_create(C.byref(h), B, H, W, Cc, P, flags), 'uh_tail_create')
         self.handle = h
@@ -480,10 +482,10 @@ class TailPlan(object):
             pass
 
     @classmethod
-    def get(cls, B, H, W, Cc, P, device, fused_patch=False, graph=True, solve_f64=False):
-        key = (B, H, W, Cc, P, str(device), bool(fused_patch), bool(graph), bool(solve_f64))
+    def get(cls, B, H, W, Cc, P, device, fused_patch=False, graph=True, solve_f64=False, zero_nonfinite_grad=False):
+        key = (B, H, W, Cc, P, str(device), bool(fused_patch), bool(graph), bool(solve_f64), bool(zero_nonfinite_grad))
         if key not in cls._cache:
-            cls._cache[key] = cls(B, H, W, Cc, P, device, fused_patch, graph, solve_f64)
+            cls._cache[key] = cls(B, H, W, Cc, P, device, fused_patch, graph, solve_f64, zero_nonfinite_grad)
         return cls._cache[key]
 
 
@@ -525,10 +527,11 @@ class _PhotometricTail(torch.autograd.Function):
         return None, (ctx.dh4p * dLoss if ctx.dh4p is not None else None), None, None, None, None
 
 
-def photometric_tail(pts1, h4p, U, I2, patch_indices, patch_size, fused_patch=False, graph=True, solve_f64=False):
+def photometric_tail(pts1, h4p, U, I2, patch_indices, patch_size, fused_patch=False, graph=True, solve_f64=False,
+                     zero_nonfinite_grad=False):
     """-> (l1_loss, pred_I2 [B,P,P,1], H_mat [B,3,3], plan).  plan.warped is the warped frame (full-frame mode)."""
     B, H, W, Cc = U.shape
-    plan = TailPlan.get(B, H, W, Cc, int(patch_size), U.device, fused_patch, graph, solve_f64)
+    plan = TailPlan.get(B, H, W, Cc, int(patch_size), U.device, fused_patch, graph, solve_f64, zero_nonfinite_grad)
     loss, pred, Hm = _PhotometricTail.apply(pts1, h4p, U, I2, patch_indices, plan)
     return loss, pred, Hm, plan
 
