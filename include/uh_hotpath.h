@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define UH_ABI_VERSION 2
+#define UH_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define UH_API __attribute__((visibility("default")))
@@ -173,6 +173,20 @@ UH_API int uh_patch_losses_forward(const float* pred, const float* target, const
 #define UH_LOSS_NCC        4
 UH_API int uh_patch_loss_backward(int kind, const float* pred, const float* target, const float* stats16,
                            const float* dLoss, float* dPred, int B, int P, uh_stream_t stream);
+/* The two launches either side of the loss, folded into their neighbours (same results, bit for bit, as the calls they
+ * replace; they exist because each of the replaced kernels is 5-7 us of launch latency for < 1 us of work):
+ *   uh_gather_patch_losses_forward = uh_gray_patch_forward + uh_patch_losses_forward: pred [B,P,P] (written) is the gray
+ *     gather of warped [B,H,W,C] at patch_idx [B,P*P], out16 as above.  Workspace: uh_patch_losses_workspace_bytes(B, P).
+ *   uh_warp_patch_loss_backward   = uh_patch_loss_backward + uh_warp_patch_backward for the point-wise kinds (REC, L1,
+ *     L1_SMOOTH, NCC; UH_E_SHAPE for SSIM, whose gradient is a stencil): dTheta [B,9] straight from (pred, target,
+ *     stats16, dLoss), no dPred tensor; dLoss == NULL means 1.  Workspace: uh_warp_patch_backward_workspace_bytes.  */
+UH_API int uh_gather_patch_losses_forward(const float* warped, const int* patch_idx, const float* target, const float* h4p,
+                                   const float* gt, float* pred, float* out16, void* workspace, size_t workspace_bytes,
+                                   int B, int H, int W, int C, int P, uh_stream_t stream);
+UH_API int uh_warp_patch_loss_backward(int kind, const float* U, const float* theta, const float* pred, const float* target,
+                                const float* stats16, const float* dLoss, const int* patch_idx, float* dTheta,
+                                void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int PP,
+                                uh_stream_t stream);
 
 /* ---- fused patch path ---------------------------------------------------------
  * For the P x P loss patch only: sample -> gray -> |pred - I2| -> loss, and d loss/d theta for

@@ -67,6 +67,14 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert lib.uh_patch_loss_backward(1, one, one, None, one, one, 2, 16, None) == -1
     assert lib.uh_warp_patch_backward(one, one, one, one, one, None, 0, 2, 16, 16, 3, 64, None) == -4
     assert lib.uh_warp_patch_backward_workspace_bytes(64, 240, 320, 3) == 64 * 5 * 15 * (9 * 4 + 4)
+    assert lib.uh_gather_patch_losses_forward(one, one, one, None, None, one, one, one, 1 << 20, 2, 16, 16, 3, 2, None) == -2   # P < 3
+    assert lib.uh_gather_patch_losses_forward(one, one, one, one, None, one, one, one, 1 << 20, 2, 16, 16, 3, 8, None) == -1   # h4p xor gt
+    assert lib.uh_gather_patch_losses_forward(one, one, one, None, None, one, one, one, 1 << 20, 2, 16, 16, 7, 8, None) == -3
+    assert lib.uh_gather_patch_losses_forward(one, one, one, None, None, one, one, None, 0, 2, 16, 16, 3, 8, None) == -4
+    assert lib.uh_warp_patch_loss_backward(1, one, one, one, one, one, None, one, one, one, 1 << 20, 2, 16, 16, 3, 64, None) == -2   # SSIM: stencil
+    assert lib.uh_warp_patch_loss_backward(2, one, one, one, one, None, None, one, one, one, 1 << 20, 2, 16, 16, 3, 64, None) == -1
+    assert lib.uh_warp_patch_loss_backward(2, one, one, one, one, one, None, one, one, None, 0, 2, 16, 16, 3, 64, None) == -4
+    assert lib.uh_tail_create(C.byref(C.c_void_p()), 4, 60, 80, 3, 2, 0) == -2                       # un-fused tail: P >= 3
     args13 = [one] * 13
     assert lib.uh_prepare_inputs(*args13, 0, 8, 8, 4, None) == -2
     assert lib.uh_prepare_inputs(*args13, 2, 8, 8, 16, None) == -2                                  # patch larger than frame

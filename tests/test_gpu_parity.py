@@ -342,9 +342,10 @@ def test_launch_profiler_reports_kernel_durations(ops, dev):
         prof = _lib.profile_read()
     finally:
         _lib.profile_enable(False)
-    for k in ('warp_forward', 'warp_backward', 'warp_backward_finish'):
+    for k in ('warp_forward', 'warp_backward'):
         ms, n = prof[k]
         assert n == 3 and 0.0 < ms / n < 5.0, (k, ms, n)
+    assert prof['warp_backward_finish'][1] == 0        # folded into the backward kernel's last block (ticket route)
 
 
 # ---------------------------------------------------------------------------------------------- warp bwd
@@ -567,6 +568,184 @@ def test_warp_gather_node_matches_two_node_chain(ops, dev):
     p2.backward(g)
     assert torch.equal(w1, w2) and torch.equal(p1, p2)
     assert torch.equal(t1.grad, t2.grad)
+
+
+# ------------------------------------------------------------------------- folded launches (last-block tickets)
+def _abi(dev):
+    from unsuperviseddeephomographyral2018_amd import _lib
+    import ctypes as C_
+    lib = _lib.load()
+    return _lib, lib, (lambda t: None if t is None else C_.c_void_p(t.data_ptr())), \
+        C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _patch_case(rs, case, B, H, W, P):
+    """index sets of the two tests above, as [B, P*P] int32"""
+    u = np.arange(P)
+    x0 = rs.randint(0, W - P + 1, B); y0 = rs.randint(0, H - P + 1, B)
+    idx = ((u[None, :, None] + y0[:, None, None]) * W + (u[None, None, :] + x0[:, None, None])).reshape(B, P * P)
+    if case == 'swaps_and_dups':
+        idx[0, [3, 17]] = idx[0, [17, 3]]; idx[1 % B, 5] = idx[1 % B, 6]
+    elif case == 'random':
+        idx = rs.randint(0, H * W, (B, P * P))
+    return idx.astype(np.int32)
+
+
+@pytest.mark.parametrize('C', [1, 3, 4])
+@pytest.mark.parametrize('B,H,W,P,case', [(3, 20, 28, 3, 'rect'), (2, 40, 52, 17, 'random'), (5, 60, 92, 33, 'swaps_and_dups'),
+                                          (8, 240, 320, 128, 'rect')])
+def test_gather_patch_losses_equals_two_launch_chain(ops, dev, B, H, W, P, case, C):
+    """uh_gather_patch_losses_forward (gray + gather + the six loss values + their finish, ONE launch) against
+    uh_gray_patch_forward -> uh_patch_losses_forward: the same pred and the same 16 outputs, bit for bit, for any index
+    set (the SSIM windows of a chunk reach into the next rows: P = 3, 17 and 33 put chunk borders everywhere)."""
+    _lib, lib, p, st = _abi(dev)
+    rs = np.random.RandomState(B * 1000 + P + C)
+    frame = T(rs.randn(B, H, W, C).astype(np.float32), dev)
+    idx = T(_patch_case(rs, case, B, H, W, P), dev)
+    y = T(rs.randn(B, P, P).astype(np.float32), dev)
+    h4p = T(rs.randn(B, 8).astype(np.float32), dev); gt = T(rs.randn(B, 8).astype(np.float32), dev)
+    nb = lib.uh_patch_losses_workspace_bytes(B, P)
+    ws = torch.empty(nb // 4, device=dev)
+    pred_a = torch.empty(B, P * P, device=dev); out_a = torch.empty(16, device=dev)
+    _lib.check(lib.uh_gray_patch_forward(p(frame), p(idx), p(pred_a), B, H, W, C, P * P, st), 'gray')
+    _lib.check(lib.uh_patch_losses_forward(p(pred_a), p(y), p(h4p), p(gt), p(out_a), p(ws), nb, B, P, st), 'losses')
+    pred_b = torch.full((B, P * P), 9.0, device=dev); out_b = torch.full((16,), 9.0, device=dev)
+    ws2 = torch.empty(nb // 4, device=dev)
+    _lib.check(lib.uh_gather_patch_losses_forward(p(frame), p(idx), p(y), p(h4p), p(gt), p(pred_b), p(out_b), p(ws2), nb,
+                                                  B, H, W, C, P, st), 'gather_losses')
+    assert torch.equal(pred_a, pred_b)
+    assert torch.equal(out_a, out_b), (out_a, out_b)
+    # the values themselves against NumPy (f64)
+    x = pred_a.cpu().numpy().astype(np.float64); yy = y.cpu().numpy().reshape(B, -1).astype(np.float64)
+    o = out_a.cpu().numpy()
+    assert abs(o[2] - np.abs(x - yy).mean()) < 1e-5 and abs(o[0] - np.sqrt(((x - yy) ** 2).mean())) < 1e-5
+    # argument errors
+    assert lib.uh_gather_patch_losses_forward(p(frame), p(idx), p(y), p(h4p), None, p(pred_b), p(out_b), p(ws2), nb,
+                                              B, H, W, C, P, st) == -1
+    assert lib.uh_gather_patch_losses_forward(p(frame), p(idx), p(y), None, None, p(pred_b), p(out_b), p(ws2), nb - 4,
+                                              B, H, W, C, P, st) == -4
+    assert lib.uh_gather_patch_losses_forward(p(frame), p(idx), p(y), None, None, p(pred_b), p(out_b), p(ws2), nb,
+                                              B, H, W, 5, P, st) == -3
+
+
+@pytest.mark.parametrize('kind', ['rec_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss'])
+@pytest.mark.parametrize('case', ['rect', 'swaps_and_dups', 'random'])
+def test_warp_patch_loss_backward_equals_two_launch_chain(ops, dev, case, kind):
+    """uh_warp_patch_loss_backward (loss gradient formed inside the sparse warp backward, finish in the last block) against
+    uh_patch_loss_backward -> uh_warp_patch_backward: bit-identical dTheta for every point-wise loss kind and every index
+    set (the stray entries' f64 path forms the same gradient); dLoss = NULL means 1; SSIM is refused."""
+    _lib, lib, p, st = _abi(dev)
+    rs = np.random.RandomState(len(kind) * 31 + len(case))
+    B, H, W, C, P = 4, 60, 92, 3, 24
+    PP = P * P
+    k = _lib.LOSS_KINDS[kind]
+    U = T(rs.randn(B, H, W, C).astype(np.float32), dev)
+    theta = (np.tile(np.eye(3), (B, 1, 1)) + 0.08 * rs.randn(B, 3, 3)).astype(np.float32)
+    theta[2] = np.array([[1, 0.05, 0], [-0.05, 1, 0], [0.8, 0.5, 0.3]], np.float32)
+    tth = T(theta.reshape(B, 9), dev)
+    idx = T(_patch_case(rs, case, B, H, W, P), dev)
+    x = T((rs.randn(B, PP) * 1.5).astype(np.float32), dev)
+    y = T((x.cpu().numpy() + rs.randn(B, PP) * rs.choice([0.05, 0.8, 2.0], size=(B, 1))).astype(np.float32), dev)
+    nbl = lib.uh_patch_losses_workspace_bytes(B, P); wsl = torch.empty(nbl // 4, device=dev)
+    stats = torch.empty(16, device=dev)
+    _lib.check(lib.uh_patch_losses_forward(p(x), p(y), None, None, p(stats), p(wsl), nbl, B, P, st), 'losses')
+    nb = lib.uh_warp_patch_backward_workspace_bytes(B, H, W, C)
+    for g in (0.37, None):
+        gl = T(np.array([g if g is not None else 1.0], np.float32), dev)
+        dP = torch.empty(B, PP, device=dev)
+        _lib.check(lib.uh_patch_loss_backward(k, p(x), p(y), p(stats), p(gl), p(dP), B, P, st), 'loss_bwd')
+        ws = torch.empty(nb // 4, device=dev); dT_a = torch.empty(B, 9, device=dev)
+        _lib.check(lib.uh_warp_patch_backward(p(U), p(tth), p(dP), p(idx), p(dT_a), p(ws), nb, B, H, W, C, PP, st), 'patch_bwd')
+        ws2 = torch.empty(nb // 4, device=dev); dT_b = torch.full((B, 9), 5.0, device=dev)
+        _lib.check(lib.uh_warp_patch_loss_backward(k, p(U), p(tth), p(x), p(y), p(stats), p(gl) if g is not None else None,
+                                                   p(idx), p(dT_b), p(ws2), nb, B, H, W, C, PP, st), 'patch_loss_bwd')
+        assert torch.equal(dT_a, dT_b), (kind, case, g, dT_a, dT_b)
+        assert float(dT_a.abs().max()) > 0
+    assert lib.uh_warp_patch_loss_backward(_lib.LOSS_KINDS['ssim_loss'], p(U), p(tth), p(x), p(y), p(stats), None, p(idx),
+                                           p(dT_b), p(ws2), nb, B, H, W, C, PP, st) == -2
+    assert lib.uh_warp_patch_loss_backward(k, p(U), p(tth), None, p(y), p(stats), None, p(idx), p(dT_b), p(ws2), nb, B, H, W,
+                                           C, PP, st) == -1
+
+
+def test_last_block_ticket_and_finish_kernel_routes_agree(ops, dev):
+    """The finish of the warp backward (dense and sparse) runs in the last block of each image when a ticket range is
+    available (B <= 4096) and as a second kernel otherwise.  A batch of 4100 small images takes the second route, its
+    two halves take the first: same bits.  Repeating a launch 40 times gives the same bits every time (the last block
+    leaves the counters at 0), also when launches of different batch sizes interleave."""
+    _lib, lib, p, st = _abi(dev)
+    rs = np.random.RandomState(5)
+    B, H, W, C, P = 4100, 16, 64, 3, 8
+    PP = P * P
+    U = T(rs.randn(B, H, W, C).astype(np.float32), dev)
+    tth = T((np.tile(np.eye(3), (B, 1, 1)) + 0.05 * rs.randn(B, 3, 3)).astype(np.float32).reshape(B, 9), dev)
+    idx = T(_patch_case(rs, 'rect', B, H, W, P), dev)
+    dP = T(rs.randn(B, PP).astype(np.float32), dev)
+    dO = T(rs.randn(B, H, W, C).astype(np.float32), dev)
+
+    def sparse(lo, hi):
+        n = hi - lo
+        nb = lib.uh_warp_patch_backward_workspace_bytes(n, H, W, C); ws = torch.empty(nb // 4, device=dev)
+        dT = torch.empty(n, 9, device=dev)
+        _lib.check(lib.uh_warp_patch_backward(p(U[lo:hi]), p(tth[lo:hi]), p(dP[lo:hi]), p(idx[lo:hi]), p(dT), p(ws), nb, n,
+                                              H, W, C, PP, st), 'patch_bwd')
+        return dT
+
+    def dense(lo, hi):
+        n = hi - lo
+        nb = lib.uh_warp_backward_workspace_bytes(n, H, W, C, H, W); ws = torch.empty(nb // 4, device=dev)
+        dT = torch.empty(n, 9, device=dev)
+        _lib.check(lib.uh_warp_backward(p(U[lo:hi]), p(tth[lo:hi]), p(dO[lo:hi]), p(dT), None, p(ws), nb, n, H, W, C, H, W, st),
+                   'warp_bwd')
+        return dT
+
+    for f in (sparse, dense):
+        whole = f(0, B)                                              # B > 4096: two kernels
+        halves = torch.cat([f(0, 2048), f(2048, B)])                 # each <= 4096: ticket route
+        assert torch.equal(whole, halves), f.__name__
+        first = f(0, 300)
+        for it in range(40):
+            if it % 3 == 0:
+                f(300, 300 + 17 + it)                                # another batch size in between
+            assert torch.equal(f(0, 300), first), (f.__name__, it)
+    # the loss kernels' ticket: 60 repeats, identical outputs
+    x = T(rs.randn(64, 128, 128).astype(np.float32), dev); y = T(rs.randn(64, 128, 128).astype(np.float32), dev)
+    nb = lib.uh_patch_losses_workspace_bytes(64, 128)
+    outs = []
+    for it in range(60):
+        ws = torch.empty(nb // 4, device=dev); out = torch.empty(16, device=dev)
+        _lib.check(lib.uh_patch_losses_forward(p(x), p(y), None, None, p(out), p(ws), nb, 64, 128, st), 'losses')
+        outs.append(out)
+    assert all(torch.equal(o, outs[0]) for o in outs)
+    l1s = [ops.l1_loss(x, y) for _ in range(30)]
+    assert all(torch.equal(v, l1s[0]) for v in l1s)
+    assert abs(float(l1s[0]) - float(outs[0][2])) < 1e-6
+
+
+@pytest.mark.parametrize('kind', ['rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss'])
+def test_warp_gather_losses_node_matches_two_node_chain(ops, dev, kind):
+    """ops.warp_gather_losses (transform() + build_losses() as one node: 2 launches forward, 1 backward) against
+    ops.warp_gather -> ops.patch_losses at the BASELINE size: same frame, same pred, same six values, same d/dtheta bits."""
+    B, H, W, P = 8, 240, 320, 128
+    d = O.synthetic_batch(6, B, H=H, W=W, P=P, rho=45)
+    U, idx, I2 = T(d['I'], dev), T(d['patch_indices'], dev), T(d['I2'], dev)
+    h4p, gt = T(d['pred_h4p'], dev), T(d['gt'], dev)
+    _, theta = ops.solve_dlt(T(d['pts1'], dev), h4p, img_w=W, img_h=H)
+    k = {'rec_loss': 0, 'ssim_loss': 1, 'l1_loss': 2, 'l1_smooth_loss': 3, 'ncc_loss': 4}[kind]
+    t1 = theta.detach().clone().requires_grad_(True); t2 = theta.detach().clone().requires_grad_(True)
+    w1, p1 = ops.warp_gather(U, t1, idx, P)
+    o1 = ops.patch_losses(p1, I2, h4p, gt, train=kind)
+    (0.6 * o1[k]).backward()
+    w2, p2, o2 = ops.warp_gather_losses(U, t2, idx, P, I2, h4p, gt, train=kind)
+    (0.6 * o2[k]).backward()
+    assert torch.equal(w1, w2) and torch.equal(p1, p2) and torch.equal(o1, o2)
+    assert torch.equal(t1.grad, t2.grad) and float(t1.grad.abs().max()) > 0
+    # a monitor element carries nothing
+    t3 = theta.detach().clone().requires_grad_(True)
+    o3 = ops.warp_gather_losses(U, t3, idx, P, I2, h4p, gt, train=kind)[2]
+    o3[(k + 1) % 5].backward()
+    assert float(t3.grad.abs().max()) == 0.0
+    # train=None: no graph at all
+    assert not ops.warp_gather_losses(U, t3, idx, P, I2, h4p, gt)[2].requires_grad
 
 
 # ---------------------------------------------------------------------------------------------- chain

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UH_LIB_PATH lets a developer A/B a differently-built copy of the SAME library (tools/); it is not a fallback.
 LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hotpath.so')
 
-UH_ABI_VERSION = 2
+UH_ABI_VERSION = 3
 UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
 UH_DLT_ZERO_NONFINITE_GRAD = 8
@@ -33,6 +33,8 @@ SIGNATURES = {
     'uh_warp_backward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),
     'uh_warp_patch_backward_workspace_bytes': (_z, [_i, _i, _i, _i]),
     'uh_warp_patch_backward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
+    'uh_gather_patch_losses_forward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
+    'uh_warp_patch_loss_backward': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
     'uh_gray_patch_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'uh_gray_patch_backward': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'uh_l1_loss_workspace_bytes': (_z, [_z]),

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/uh_hotpath.h"
 
 #define UH_WAVE 64
 
@@ -337,5 +338,85 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // wave index of this thread as a scalar (threadIdx.x >> 6 is wave-uniform but the compiler cannot know)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// ---- "the block that takes the last ticket finishes" -------------------------------------------------------------------
+// A reduction whose second stage used to be a one-block finish KERNEL (5-7 us of launch latency for < 1 us of work) ends
+// in its producer instead: every block publishes its partial sums, takes a ticket from a device counter, and the block
+// that draws the last one reads all partials back and writes the result.  gfx950 has 8 XCDs with one L2 each and no
+// coherence between them for ordinary accesses, so
+//   * partials are published with agent-scope atomic EXCHANGES (performed at the memory side, past the L2s; a returned
+//     value means the write is done) -- not plain stores + __threadfence(), whose release would write back the whole L2;
+//   * the finishing block reads them with agent-scope atomic loads (sc1: they do not hit a stale line of its own L2);
+//   * the counter is an agent-scope atomic add; the last block resets it to 0, so a counter is 0 between launches.
+// The counters live in a library-owned pool (uh::ticket_slots, uh_misc.hip).
+__device__ __forceinline__ void publish_i32(int* p, int v) {
+    const int old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" :: "v"(old));                             // ask for the returned value: its arrival = the exchange is done
+}
+__device__ __forceinline__ void publish_f32(float* p, float v) { publish_i32((int*)p, __float_as_int(v)); }
+template <bool COHERENT>
+__device__ __forceinline__ float read_f32(const float* p) {
+    if constexpr (COHERENT) return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+}
+template <bool COHERENT>
+__device__ __forceinline__ int read_i32(const int* p) {
+    if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+// Whole block calls it after its publish_*() calls; true (in every thread) in the block that took ticket `target - 1`.
+__device__ __forceinline__ bool take_last_ticket(int* ticket, int target, int* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's exchanges have returned = are performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == target - 1;
+        if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_flag = last;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+// LDS hand-over between the lanes of ONE wave (its ds ops execute in order; this only stops the compiler reordering)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- point-wise photometric loss gradients (shared by uh_patch_loss_backward and uh_warp_patch_loss_backward) -------------
+// dPred_p = dLoss * f(x_p, y_p; global sums), x = pred_I2, y = I2_aug, N = B*P*P, stats = the 16 floats of
+// uh_patch_losses_forward:
+//   rec    : d / (N rec)                      rec = sqrt(mean d^2)                              (homography_model.py:303)
+//   l1     : sign(d) / N                                                                        (:328)
+//   smooth : (|d| < 1 ? d : sign(d)) / N                                                        (:136-139)
+//   ncc    : -(1/ncc) [ (y/|y| - x/|x|)/|x| - x (<x,y>/|y| - |x|)/|x|^3 ]                        (:161-166)
+// A zero norm (rec == 0, ncc == 0, |x| == 0) is 0/0 in the reference's autodiff; 0 is written here.
+struct LossCoef { float c0, c1, c2; };
+__device__ __forceinline__ LossCoef loss_coef(int kind, const float* __restrict__ stats, float g, size_t n) {
+    LossCoef c{0.f, 0.f, 0.f};
+    const float inv_n = 1.0f / (float)n;
+    if (kind == UH_LOSS_REC) {
+        const float rec = stats[0];
+        c.c0 = rec > 0.f ? g * inv_n / rec : 0.f;
+    } else if (kind == UH_LOSS_NCC) {
+        const float lx = sqrtf(stats[9]), ly = sqrtf(stats[10]), sxy = stats[11], ncc = stats[4];
+        if (lx > 0.f && ly > 0.f && ncc > 0.f) {
+            const float k = -g / ncc;
+            c.c0 = k / (lx * ly);                                   // * y
+            c.c1 = -k / (lx * lx) - k * (sxy / ly - lx) / (lx * lx * lx);   // * x
+        }
+    } else {
+        c.c2 = g * inv_n;
+    }
+    return c;
+}
+__device__ __forceinline__ float loss_grad_point(int kind, float x, float y, const LossCoef& c) {
+    const float d = x - y;
+    if (kind == UH_LOSS_REC) return c.c0 * d;
+    if (kind == UH_LOSS_NCC) return c.c0 * y + c.c1 * x;
+    if (kind == UH_LOSS_L1) return d > 0.f ? c.c2 : (d < 0.f ? -c.c2 : 0.f);
+    return fabsf(d) < 1.0f ? c.c2 * d : (d > 0.f ? c.c2 : -c.c2);
+}
 
 }  // namespace uh

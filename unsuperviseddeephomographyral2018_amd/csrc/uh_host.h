@@ -31,10 +31,36 @@ inline void launch_timed(int kid, K kernel, dim3 grid, dim3 block, hipStream_t s
     }
 }
 
+// same, with `shm` bytes of dynamic LDS
+template <typename K, typename... Args>
+inline void launch_timed_shm(int kid, K kernel, dim3 grid, dim3 block, unsigned shm, hipStream_t s, Args... args) {
+    if (g_prof_on && ((g_prof_mask >> kid) & 1u)) {
+        hipEvent_t a, b;
+        prof_pair(kid, &a, &b);
+        hipExtLaunchKernelGGL(kernel, grid, block, shm, s, a, b, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shm, s, args...);
+    }
+}
+
 struct ProfScope {
     int k; hipStream_t s; bool on;
     ProfScope(int kernel, hipStream_t stream) : k(kernel), s(stream), on(g_prof_on && ((g_prof_mask >> kernel) & 1u)) { if (on) prof_begin(k, s); }
     ~ProfScope() { if (on) prof_end(k, s); }
 };
+
+// `n` device ints that are 0 now and 0 again after the kernel that uses them as last-block tickets (uh_device.h,
+// take_last_ticket).  Library-owned pool per device, handed out round-robin: a range can only be handed out twice at
+// once if more than TICKET_POOL / n such launches are in flight on DIFFERENT streams.  nullptr when n is too large or
+// when the pool does not exist yet and `s` is being captured (hipMalloc is not capturable) -- the caller then launches
+// the separate finish kernel instead.
+constexpr int TICKET_POOL = 16384;
+int* ticket_slots(int n, hipStream_t s);
+
+// uh_gather_patch_losses_forward with a second destination for l1_loss (uh_tail.hip writes the caller's loss scalar
+// from the loss kernel itself instead of a 4-byte copy node)
+int gather_patch_losses(const float* warped, const int* patch_idx, const float* target, const float* h4p, const float* gt,
+                        float* pred, float* out16, float* l1_out, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                        int C, int P, hipStream_t stream);
 
 }  // namespace uh

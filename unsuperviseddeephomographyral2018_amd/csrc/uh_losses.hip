@@ -21,16 +21,89 @@ namespace uh {
 constexpr int NLS = 7;      // |d|, d^2, smooth-l1, x^2, y^2, x*y, ssim
 constexpr int LPT = 4;      // patch pixels per thread of patch_losses_kernel
 
+// out[0..4] = rec, ssim, l1, l1_smooth, ncc;  out[5] = h_loss = sqrt(mean((h4p - gt)^2)) when h4p != NULL.
+// One block of 256 threads.  COHERENT: the partials come from other blocks of the running kernel (last-block ticket).
+struct LossFinish { const float* h4p; const float* gt; int nh; float* out; double inv_n, inv_ns;
+                    float* l1_out; };      // optional second destination of l1_loss (uh_tail: the caller's loss scalar)
+template <bool COHERENT>
+__device__ __forceinline__ void patch_losses_finish(const float* __restrict__ partial, int nblk, const LossFinish& f,
+                                                    double (*red)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a[NLS + 1];
+#pragma unroll
+    for (int k = 0; k <= NLS; ++k) a[k] = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+#pragma unroll
+        for (int k = 0; k < NLS; ++k) a[k] += (double)read_f32<COHERENT>(partial + (size_t)i * NLS + k);
+    }
+    if (f.h4p) for (int i = threadIdx.x; i < f.nh; i += 256) { const double d = (double)f.h4p[i] - (double)f.gt[i]; a[NLS] += d * d; }
+#pragma unroll
+    for (int k = 0; k <= NLS; ++k) {
+        const double s = wave_sum(a[k]);
+        if (lane == 0) red[k][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* out = f.out;
+        double s[NLS + 1];
+#pragma unroll
+        for (int k = 0; k <= NLS; ++k) s[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+        out[0] = (float)sqrt(s[1] * f.inv_n);
+        out[1] = (float)(s[6] * f.inv_ns);
+        out[2] = (float)(s[0] * f.inv_n);
+        if (f.l1_out) *f.l1_out = out[2];
+        out[3] = (float)(s[2] * f.inv_n);
+        const double den = sqrt(s[3] * s[4]);
+        const double c = den > 0.0 ? s[5] / den : 0.0;          // x or y identically 0: the reference yields NaN; monitor only
+        out[4] = (float)sqrt(fmax(0.0, 2.0 - 2.0 * c));
+        out[5] = f.h4p ? (float)sqrt(s[NLS] / (double)f.nh) : 0.f;
+        // raw sums for uh_patch_loss_backward (the global norms of rec / ncc): |d|, d^2, smooth, x^2, y^2, xy, ssim
+#pragma unroll
+        for (int k = 0; k < NLS; ++k) out[6 + k] = (float)s[k];
+        out[13] = 0.f; out[14] = 0.f; out[15] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void patch_losses_finish_kernel(const float* __restrict__ partial, int nblk, LossFinish f) {
+    __shared__ double red[NLS + 1][4];
+    patch_losses_finish<false>(partial, nblk, f, red);
+}
+
 // one thread per patch pixel (i, j): its point-wise terms, plus the SSIM of the 3x3 window whose top-left
 // corner it is (i, j < P-2).  The 2 x 9 window taps come from L1/L2 (the patch is 64 KiB per image).
+// GC > 0 (uh_gather_patch_losses_forward): X is not pred_I2 but the warped FRAME [B,H,W,GC]; the block first forms its
+// pixels' pred = gray(frame[patch_idx]) (reduce_mean(axis=3) + gather, homography_model.py:263-269 -- the arithmetic of
+// gray_patch_forward_kernel), writes them to `pred`, and keeps them -- with the two rows + two pixels after its chunk
+// that its SSIM windows reach into -- in LDS.  Same statistics, bit for bit, as gather kernel + this kernel on pred.
+struct GatherArgs { const int* idx; float* pred; int HW; };
+template <int GC>
 __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restrict__ X, const float* __restrict__ Y,
-                                                           float* __restrict__ partial, int P, int blocks_per_image) {
+                                                           float* __restrict__ partial, int P, int blocks_per_image,
+                                                           int* ticket, LossFinish fin, GatherArgs ga) {
     __shared__ float red[NLS][16];
+    extern __shared__ float xt[];                 // GC > 0: LPT*256 + 2P + 3 floats
     const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x - b * blocks_per_image;
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int n = P * P;
+    const int c0 = chunk * LPT * 256;
     const float* __restrict__ x = X + (size_t)b * n;
     const float* __restrict__ y = Y + (size_t)b * n;
+    if constexpr (GC > 0) {
+        const int m = min(n - c0, LPT * 256 + 2 * P + 3);
+        const int* __restrict__ idx = ga.idx + (size_t)b * n + c0;
+        const float* __restrict__ frame = X + (size_t)b * ga.HW * GC;
+        float* __restrict__ pred = ga.pred + (size_t)b * n + c0;
+        for (int t = threadIdx.x; t < m; t += 256) {
+            const float* q = frame + (size_t)idx[t] * GC;
+            float s = q[0];
+#pragma unroll
+            for (int c = 1; c < GC; ++c) s = s + q[c];
+            const float v = s / (float)GC;
+            xt[t] = v;
+            if (t < LPT * 256) pred[t] = v;
+        }
+        __syncthreads();
+    }
+    auto xat = [&](int e) { if constexpr (GC > 0) return xt[e - c0]; else return x[e]; };
     float acc[NLS];
 #pragma unroll
     for (int k = 0; k < NLS; ++k) acc[k] = 0.f;
@@ -40,7 +113,7 @@ __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restri
     const int e = (chunk * LPT + q) * 256 + (int)threadIdx.x;
     if (e < n) {
         const int i = e / P, j = e - i * P;
-        const float xv = x[e], yv = y[e];
+        const float xv = xat(e), yv = y[e];
         const float d = xv - yv, ad = fabsf(d);
         acc[0] += ad; acc[1] += d * d;
         acc[2] += ad < 1.0f ? 0.5f * (ad * ad) : ad - 0.5f;
@@ -51,7 +124,7 @@ __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restri
             for (int u = 0; u < 3; ++u)
 #pragma unroll
                 for (int v = 0; v < 3; ++v) {
-                    const float a = x[e + u * P + v], c = y[e + u * P + v];
+                    const float a = xat(e + u * P + v), c = y[e + u * P + v];
                     sx += a; sy += c; sxx += a * a; syy += c * c; sxy += a * c;
                 }
             const float inv9 = 1.0f / 9.0f;
@@ -74,84 +147,27 @@ __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restri
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += r[k];
-        partial[(size_t)blockIdx.x * NLS + threadIdx.x] = t;
+        if (ticket) publish_f32(partial + (size_t)blockIdx.x * NLS + threadIdx.x, t);
+        else partial[(size_t)blockIdx.x * NLS + threadIdx.x] = t;
     }
-}
-
-// out[0..4] = rec, ssim, l1, l1_smooth, ncc;  out[5] = h_loss = sqrt(mean((h4p - gt)^2)) when h4p != NULL.
-__global__ __launch_bounds__(256) void patch_losses_finish_kernel(const float* __restrict__ partial, int nblk,
-                                                                  const float* __restrict__ h4p,
-                                                                  const float* __restrict__ gt, int nh,
-                                                                  float* __restrict__ out, double inv_n, double inv_ns) {
-    __shared__ double red[NLS + 1][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double a[NLS + 1];
-#pragma unroll
-    for (int k = 0; k <= NLS; ++k) a[k] = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) {
-#pragma unroll
-        for (int k = 0; k < NLS; ++k) a[k] += (double)partial[(size_t)i * NLS + k];
-    }
-    if (h4p) for (int i = threadIdx.x; i < nh; i += 256) { const double d = (double)h4p[i] - (double)gt[i]; a[NLS] += d * d; }
-#pragma unroll
-    for (int k = 0; k <= NLS; ++k) {
-        const double s = wave_sum(a[k]);
-        if (lane == 0) red[k][wave] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s[NLS + 1];
-#pragma unroll
-        for (int k = 0; k <= NLS; ++k) s[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
-        out[0] = (float)sqrt(s[1] * inv_n);
-        out[1] = (float)(s[6] * inv_ns);
-        out[2] = (float)(s[0] * inv_n);
-        out[3] = (float)(s[2] * inv_n);
-        const double den = sqrt(s[3] * s[4]);
-        const double c = den > 0.0 ? s[5] / den : 0.0;          // x or y identically 0: the reference yields NaN; monitor only
-        out[4] = (float)sqrt(fmax(0.0, 2.0 - 2.0 * c));
-        out[5] = h4p ? (float)sqrt(s[NLS] / (double)nh) : 0.f;
-        // raw sums for uh_patch_loss_backward (the global norms of rec / ncc): |d|, d^2, smooth, x^2, y^2, xy, ssim
-#pragma unroll
-        for (int k = 0; k < NLS; ++k) out[6 + k] = (float)s[k];
-        out[13] = 0.f; out[14] = 0.f; out[15] = 0.f;
+    // last-block ticket (uh_device.h): the block that completes the grid computes the 16 outputs itself -- same code and
+    // summation order as patch_losses_finish_kernel, without that kernel's launch
+    if (ticket) {
+        __shared__ int last_flag;
+        __shared__ double fred[NLS + 1][4];
+        if (take_last_ticket(ticket, (int)gridDim.x, &last_flag)) patch_losses_finish<true>(partial, (int)gridDim.x, fin, fred);
     }
 }
 
 // ---- gradients -------------------------------------------------------------------------------------------------
-// Point-wise losses: dPred_p = dLoss * f(x_p, y_p; global sums).  N = B*P*P.
-//   rec    : d / (N rec)                      rec = sqrt(mean d^2)                              (:303)
-//   l1     : sign(d) / N                                                                        (:328)
-//   smooth : (|d| < 1 ? d : sign(d)) / N                                                        (:136-139)
-//   ncc    : -(1/ncc) [ (y/|y| - x/|x|)/|x| - x (<x,y>/|y| - |x|)/|x|^3 ]                        (:161-166)
-// A zero norm (rec == 0, ncc == 0, |x| == 0) is 0/0 in the reference's autodiff; 0 is written here.
+// Point-wise losses (loss_coef / loss_grad_point in uh_device.h).
 template <int KIND>
 __global__ __launch_bounds__(256) void patch_loss_backward_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ dLoss,
                                                                   float* __restrict__ dX, size_t n) {
-    const float g = dLoss[0], inv_n = 1.0f / (float)n;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    if (KIND == UH_LOSS_REC) {
-        const float rec = stats[0];
-        c0 = rec > 0.f ? g * inv_n / rec : 0.f;
-    } else if (KIND == UH_LOSS_NCC) {
-        const float lx = sqrtf(stats[9]), ly = sqrtf(stats[10]), sxy = stats[11], ncc = stats[4];
-        if (lx > 0.f && ly > 0.f && ncc > 0.f) {
-            const float k = -g / ncc;
-            c0 = k / (lx * ly);                                   // * y
-            c1 = -k / (lx * lx) - k * (sxy / ly - lx) / (lx * lx * lx);   // * x
-        }
-    } else {
-        c2 = g * inv_n;
-    }
-    auto grad = [&](float x, float y) {
-        const float d = x - y;
-        if (KIND == UH_LOSS_REC) return c0 * d;
-        if (KIND == UH_LOSS_NCC) return c0 * y + c1 * x;
-        if (KIND == UH_LOSS_L1) return d > 0.f ? c2 : (d < 0.f ? -c2 : 0.f);
-        return fabsf(d) < 1.0f ? c2 * d : (d > 0.f ? c2 : -c2);
-    };
+    const LossCoef lc = loss_coef(KIND, stats, dLoss[0], n);
+    auto grad = [&](float x, float y) { return loss_grad_point(KIND, x, y, lc); };
     // 16 bytes per lane (the patch tensors are 16-byte aligned whenever P*P % 4 == 0; hipMalloc / torch allocations are)
     const size_t n4 = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dX)) & 15) ? 0 : n / 4;
     const float4* X4 = reinterpret_cast<const float4*>(X);
@@ -266,20 +282,57 @@ extern "C" int uh_patch_loss_backward(int kind, const float* pred, const float* 
     return (int)hipGetLastError();
 }
 
+static int launch_losses(const float* X, const float* target, const float* h4p, const float* gt, float* out16, void* workspace,
+                         int B, int P, hipStream_t s, int GC, GatherArgs ga, float* l1_out = nullptr) {
+    const int bpi = (P * P + 256 * LPT - 1) / (256 * LPT);
+    const LossFinish fin{h4p, gt, B * 8, out16, 1.0 / ((double)B * P * P), 1.0 / ((double)B * (P - 2) * (P - 2)), l1_out};
+    int* ticket = ticket_slots(1, s);            // NULL (first call inside a stream capture): separate finish kernel
+    const unsigned shm = GC ? (unsigned)((LPT * 256 + 2 * P + 3) * sizeof(float)) : 0u;
+#define UH_LOSSES(GCV) launch_timed_shm(UH_K_LOSSES, patch_losses_kernel<GCV>, dim3((unsigned)B * bpi), dim3(256), shm, s, X, target, \
+                                        (float*)workspace, P, bpi, ticket, fin, ga)
+    switch (GC) {
+        case 0: UH_LOSSES(0); break;
+        case 1: UH_LOSSES(1); break;
+        case 2: UH_LOSSES(2); break;
+        case 3: UH_LOSSES(3); break;
+        default: UH_LOSSES(4); break;
+    }
+#undef UH_LOSSES
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ticket) return (int)e;
+    launch_timed(UH_K_LOSSES_FIN, patch_losses_finish_kernel, dim3(1), dim3(256), s, (const float*)workspace, B * bpi, fin);
+    return (int)hipGetLastError();
+}
+
 extern "C" int uh_patch_losses_forward(const float* pred, const float* target, const float* h4p, const float* gt,
-                                       float* out6, void* workspace, size_t workspace_bytes, int B, int P,
+                                       float* out16, void* workspace, size_t workspace_bytes, int B, int P,
                                        uh_stream_t stream) {
-    if (!pred || !target || !out6) return UH_E_NULL;
+    if (!pred || !target || !out16) return UH_E_NULL;
     if ((h4p == nullptr) != (gt == nullptr)) return UH_E_NULL;
     if (B <= 0 || P < 3) return UH_E_SHAPE;
     if ((uint64_t)B * P * P >= (1ull << 31)) return UH_E_TOO_LARGE;
     if (!workspace || workspace_bytes < uh_patch_losses_workspace_bytes(B, P)) return UH_E_WORKSPACE;
-    const int bpi = (P * P + 256 * LPT - 1) / (256 * LPT);
-    hipStream_t s = (hipStream_t)stream;
-    launch_timed(UH_K_LOSSES, patch_losses_kernel, dim3((unsigned)B * bpi), dim3(256), s, pred, target, (float*)workspace, P, bpi);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    launch_timed(UH_K_LOSSES_FIN, patch_losses_finish_kernel, dim3(1), dim3(256), s, (const float*)workspace, B * bpi, h4p, gt,
-                 B * 8, out6, 1.0 / ((double)B * P * P), 1.0 / ((double)B * (P - 2) * (P - 2)));
-    return (int)hipGetLastError();
+    return launch_losses(pred, target, h4p, gt, out16, workspace, B, P, (hipStream_t)stream, 0, GatherArgs{nullptr, nullptr, 0});
+}
+
+namespace uh {
+int gather_patch_losses(const float* warped, const int* patch_idx, const float* target, const float* h4p, const float* gt,
+                        float* pred, float* out16, float* l1_out, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                        int C, int P, hipStream_t stream) {
+    if (!warped || !patch_idx || !target || !pred || !out16) return UH_E_NULL;
+    if ((h4p == nullptr) != (gt == nullptr)) return UH_E_NULL;
+    if (B <= 0 || P < 3 || H <= 0 || W <= 0) return UH_E_SHAPE;
+    if (C < 1 || C > 4) return UH_E_CHANNELS;
+    if ((uint64_t)B * P * P >= (1ull << 31) || (uint64_t)H * W >= (1ull << 31)) return UH_E_TOO_LARGE;
+    if ((size_t)(LPT * 256 + 2 * P + 3) * sizeof(float) > 60 * 1024) return UH_E_TOO_LARGE;       // the chunk + its SSIM halo in LDS
+    if (!workspace || workspace_bytes < uh_patch_losses_workspace_bytes(B, P)) return UH_E_WORKSPACE;
+    return launch_losses(warped, target, h4p, gt, out16, workspace, B, P, stream, C, GatherArgs{patch_idx, pred, H * W}, l1_out);
+}
+}  // namespace uh
+
+extern "C" int uh_gather_patch_losses_forward(const float* warped, const int* patch_idx, const float* target, const float* h4p,
+                                              const float* gt, float* pred, float* out16, void* workspace,
+                                              size_t workspace_bytes, int B, int H, int W, int C, int P, uh_stream_t stream) {
+    return gather_patch_losses(warped, patch_idx, target, h4p, gt, pred, out16, nullptr, workspace, workspace_bytes, B, H, W, C, P,
+                               (hipStream_t)stream);
 }

@@ -4,9 +4,9 @@
 // i.e. solve_DLT + transform + the l1 branch of build_losses and TF's backward of them
 // (/root/reference/code/homography_model.py:169-269, 321-330).  Because the loss is a scalar and the chain is
 // evaluated at dLoss = 1, the backward does not have to wait for autograd: the caller scales dh4p by the incoming
-// gradient.  The 9 kernels + 1 memset of the un-fused chain (4 kernels with the fused patch kernel) are stream-captured
-// once per distinct argument set and replayed with hipGraphLaunch: one host call and one launch per step instead
-// of ten ctypes round trips, and no inter-kernel launch gaps on the stream.
+// gradient.  The 5 kernels of the un-fused chain (DLT, warp, gather+losses, loss-gradient+warp
+// backward, DLT backward; 4 kernels with the fused patch kernel) are stream-captured once per distinct argument set and
+// replayed with hipGraphLaunch: one host call and one launch per step, and no inter-kernel launch gaps on the stream.
 #include "uh_device.h"
 #include "uh_host.h"
 #include <mutex>
@@ -17,7 +17,7 @@ struct uh_tail_plan {
     int B, H, W, C, P;
     unsigned flags;
     // workspace layout (byte offsets, 256-byte aligned)
-    size_t off_theta, off_dtheta, off_warped, off_dpred, off_ws_warp, off_ws_l1, off_ws_patch, off_one, total;
+    size_t off_theta, off_dtheta, off_warped, off_stats, off_ws_warp, off_ws_loss, off_ws_patch, total;
     // A captured graph bakes in every kernel ARGUMENT: the pointers and the M / Minv constants (passed by value to the
     // DLT kernels).  The key therefore holds both; a caller that re-runs a plan with different M_host contents gets a
     // fresh capture, never stale constants.
@@ -34,21 +34,21 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" int uh_tail_create(uh_tail_plan** out, int B, int H, int W, int C, int P, unsigned flags) {
     if (!out) return UH_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || P <= 0 || P > H || P > W) return UH_E_SHAPE;
+    if (!(flags & UH_TAIL_FUSED_PATCH) && P < 3) return UH_E_SHAPE;       // the loss kernel also forms the 3x3 SSIM monitor
     if (C < 1 || C > 4) return UH_E_CHANNELS;
     if (uh_warp_backward_workspace_bytes(B, H, W, C, H, W) == 0) return UH_E_TOO_LARGE;
     uh_tail_plan* p = new uh_tail_plan();
     p->B = B; p->H = H; p->W = W; p->C = C; p->P = P; p->flags = flags;
     const bool fused = flags & UH_TAIL_FUSED_PATCH;
-    const size_t frame = (size_t)B * H * W * C * sizeof(float), patch = (size_t)B * P * P * sizeof(float);
+    const size_t frame = (size_t)B * H * W * C * sizeof(float);
     size_t o = 0;
     p->off_theta = o;   o = align256(o + (size_t)B * 9 * sizeof(float));
     p->off_dtheta = o;  o = align256(o + (size_t)B * 9 * sizeof(float));
-    p->off_one = o;     o = align256(o + sizeof(float));
     p->off_warped = o;  o = align256(o + (fused ? 0 : frame));
-    // (no dWarped frame: the backward takes dPred directly -- uh_warp_patch_backward)
-    p->off_dpred = o;   o = align256(o + (fused ? 0 : patch));
+    // (no dWarped frame and no dPred: the backward forms the loss gradient itself -- uh_warp_patch_loss_backward)
+    p->off_stats = o;   o = align256(o + (fused ? 0 : 16 * sizeof(float)));
     p->off_ws_warp = o; o = align256(o + (fused ? 0 : uh_warp_patch_backward_workspace_bytes(B, H, W, C)));
-    p->off_ws_l1 = o;   o = align256(o + (fused ? 0 : uh_l1_loss_workspace_bytes((size_t)B * P * P)));
+    p->off_ws_loss = o; o = align256(o + (fused ? 0 : uh_patch_losses_workspace_bytes(B, P)));
     p->off_ws_patch = o; o = align256(o + (fused ? uh_warp_patch_l1_workspace_bytes(B, P * P) : 0));
     p->total = o;
     *out = p;
@@ -88,19 +88,15 @@ static int enqueue_chain(const uh_tail_plan* p, const float* pts1, const float* 
                                          uh_warp_patch_l1_workspace_bytes(B, PP), B, H, W, C, PP, s))) return e;
     } else {
         float* warped = (float*)(ws + p->off_warped);
-        float* dpred = (float*)(ws + p->off_dpred);
-        float* one = (float*)(ws + p->off_one);
-        const size_t n = (size_t)B * PP;
+        float* stats = (float*)(ws + p->off_stats);
         if ((e = uh_warp_forward(U, theta, warped, nullptr, B, H, W, C, H, W, s))) return e;
-        if ((e = uh_gray_patch_forward(warped, idx, pred, B, H, W, C, PP, s))) return e;
-        if ((e = uh_l1_loss_forward(pred, I2, loss, ws + p->off_ws_l1, uh_l1_loss_workspace_bytes(n), n, s))) return e;
+        // gray + gather + all loss values in one launch (its finish runs in the last block and also writes `loss`)
+        if ((e = uh::gather_patch_losses(warped, idx, I2, nullptr, nullptr, pred, stats, loss, ws + p->off_ws_loss,
+                                         uh_patch_losses_workspace_bytes(B, P), B, H, W, C, P, s))) return e;
         if (dh4p) {
-            hipError_t he = hipMemsetD32Async((hipDeviceptr_t)one, 0x3f800000, 1, s);      // dLoss = 1.0f
-            if (he != hipSuccess) return (int)he;
-            if ((e = uh_l1_loss_backward(pred, I2, one, dpred, n, s))) return e;
-            // tf.gather's scatter + the dense warp backward, without the 79 %-zero frame in between
-            if ((e = uh_warp_patch_backward(U, theta, dpred, idx, dtheta, ws + p->off_ws_warp,
-                                            uh_warp_patch_backward_workspace_bytes(B, H, W, C), B, H, W, C, PP, s))) return e;
+            // loss gradient (dLoss = NULL: 1) + tf.gather's scatter + the warp backward in one launch: no dPred, no frame
+            if ((e = uh_warp_patch_loss_backward(UH_LOSS_L1, U, theta, pred, I2, stats, nullptr, idx, dtheta, ws + p->off_ws_warp,
+                                                 uh_warp_patch_backward_workspace_bytes(B, H, W, C), B, H, W, C, PP, s))) return e;
         }
     }
     if (dh4p) {

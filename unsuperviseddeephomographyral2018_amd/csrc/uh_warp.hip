@@ -423,12 +423,140 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
 // PATCH launches only the block tiles that can touch the rectangle: nrx x nry per image, anchored at the tile holding
 // (x0, y0).  The finish kernel treats every other tile's partial as the 0 the dense kernel would have written there
 // WITHOUT reading it (same summation order, same bits, no memset of the partial buffer).
-struct PatchArgs { const int* idx; int P, PP; int* confirmed; int nrx, nry; };
+struct PatchArgs { const int* idx; int P, PP; int* confirmed; int nrx, nry;
+                   int* ticket; float* dTheta;        // ticket != NULL (both modes): the image's last block also finishes it
+                   int kind; const float* pred; const float* target; const float* stats; const float* dLoss; size_t n; };
 __host__ __device__ inline void patch_tile_range(int x0, int y0, int P, int tiles_x, int tiles_y, int th, int& txlo, int& txhi,
                                                  int& tylo, int& tyhi) {
     txlo = x0 / (NWAVE * TW); txhi = min((x0 + P - 1) / (NWAVE * TW), tiles_x - 1);
     tylo = y0 / th;           tyhi = min((y0 + P - 1) / th, tiles_y - 1);
 }
+// Deterministic finish: dTheta[b][j] = sum over the image's tiles, accumulated in f64, fixed order.
+// One wave per image.  The image's partials are `tiles*9` contiguous floats; lane l < 63 walks them
+// with stride 63 (= 7*9), so its accumulator index j = l % 9 never changes and every load instruction
+// is coalesced and independent of the others; the 7 lanes that share a j then meet in LDS.
+// PATCH mode adds the entries the bandwidth kernel could not take (not at their rectangle position): if the image's
+// confirmed count falls short of PP, the wave walks the PP entries and samples the stray ones itself (literal path C
+// arithmetic, f64 accumulation, fixed order).  For the dataloader's rectangles nothing is added.
+// Where the patch gradient comes from: kind < 0 -> dPred [B,PP] as given; kind = UH_LOSS_* (point-wise kinds) -> formed on
+// the fly from (pred, target, lc) exactly as uh_patch_loss_backward would have written it (uh_warp_patch_loss_backward).
+struct LossSrc { int kind; const float* pred; const float* target; LossCoef lc; };
+__device__ __forceinline__ float patch_grad(const LossSrc& ls, const float* __restrict__ dPred, size_t e) {
+    return ls.kind < 0 ? dPred[e] : loss_grad_point(ls.kind, ls.pred[e], ls.target[e], ls.lc);
+}
+struct PatchFinish { const float* U; const float* theta; const float* dPred; const int* idx; const int* confirmed;
+                     int P, PP, H, W; float sx, sy; int tiles_x; LossSrc ls; };
+// `red` = 64 doubles of LDS private to the calling wave.  COHERENT: the partials were published by OTHER blocks of the
+// running kernel (last-block ticket, uh_device.h) and are read with agent-scope loads.
+template <int C, bool PATCH, bool COHERENT>
+__device__ __forceinline__ void finish_image(const float* __restrict__ partial, float* __restrict__ dTheta, int tiles, int b,
+                                             const PatchFinish& pf, double* red, int lane) {
+    double a = 0.0;
+    int txlo = 0, txhi = -1, tylo = 0, tyhi = -1;                        // PATCH: the tiles the bandwidth kernel wrote
+    if constexpr (PATCH) {
+        if (pf.P > 0) {
+            const int o = pf.idx[(size_t)b * pf.PP];
+            patch_tile_range(o - (o / pf.W) * pf.W, o / pf.W, pf.P, pf.tiles_x, tiles / pf.tiles_x, TH_B, txlo, txhi, tylo, tyhi);
+        }
+    }
+    auto written = [&](int tile) {                                       // every other partial counts as 0 (and is never read)
+        if constexpr (!PATCH) return true;
+        const int ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
+        return tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi;
+    };
+    if (lane < 63) {
+        const float* p = partial + (size_t)b * tiles * 9;
+        const int n = tiles * 9;
+        if constexpr (PATCH) {
+            // e advances by 63 = 7 tiles: walk (tx, ty) incrementally instead of dividing per element
+            int tile = lane / 9, ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
+            for (int e = lane; e < n; e += 63) {
+                if (tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi) a += (double)read_f32<COHERENT>(p + e);
+                tx += 7;
+                while (tx >= pf.tiles_x) { tx -= pf.tiles_x; ++ty; }
+            }
+        } else {
+#pragma unroll 4
+            for (int e = lane; e < n; e += 63) a += (double)read_f32<COHERENT>(p + e);
+        }
+    }
+    red[lane] = a;
+    double extra = 0.0;                                                  // lane j < 9: stray entries' share of sum j
+    if constexpr (PATCH) {
+        {
+            int cnt = 0;
+            for (int e = lane; e < tiles; e += 64) cnt += written(e) ? read_i32<COHERENT>(pf.confirmed + (size_t)b * tiles + e) : 0;
+            cnt = (int)wave_sum((double)cnt);
+            if (cnt != pf.PP) {
+                const int H = pf.H, W = pf.W, P = pf.P, PP = pf.PP;
+                const int* idx = pf.idx + (size_t)b * PP;
+                const int o = idx[0];
+                const int y0 = o / W, x0 = o - y0 * W;
+                const Theta th = load_theta(pf.theta, b);
+                const SrcGeom g = make_geom<C>(W, H);
+                const float* Ub = pf.U + (size_t)b * H * W * C;
+                const float halfW = (float)W * 0.5f, halfH = (float)H * 0.5f;
+                double acc[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) acc[j] = 0.0;
+                for (int e = lane; e < PP; e += 64) {
+                    const int t = idx[e];
+                    bool direct = false;
+                    if (P > 0) {
+                        const int v = e / P, u = e - v * P;
+                        direct = (x0 + u < W) && (y0 + v < H) && t == (y0 + v) * W + (x0 + u);
+                    }
+                    if (direct) continue;
+                    const int row = t / W, col = t - row * W;
+                    const float gx = lin_at(pf.sx, col), gy = lin_at(pf.sy, row);
+                    const Coord c = make_coord(th, th.a[0] * gx, th.a[3] * gx, th.a[6] * gx, gy, g);
+                    const float gv = patch_grad(pf.ls, pf.dPred, (size_t)b * PP + e) / (float)C;
+                    const size_t ia = ((size_t)c.y0f * W + (size_t)c.x0f) * C, ib = ((size_t)c.y1f * W + (size_t)c.x0f) * C;
+                    const size_t ic = ((size_t)c.y0f * W + (size_t)c.x1f) * C, id = ((size_t)c.y1f * W + (size_t)c.x1f) * C;
+                    const float hx = c.x1f - c.x0f, hy = c.y1f - c.y0f;
+                    float s1 = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                        const float Ia = Ub[ia + ch], Ib = Ub[ib + ch], Ic = Ub[ic + ch], Id = Ub[id + ch];
+                        const float ddb = Id - Ib, ddc = Id - Ic, u = (Ic - Ia) - ddb;
+                        s1 = fmaf(gv, u, s1); sb = fmaf(gv, ddb, sb); sc = fmaf(gv, ddc, sc);
+                    }
+                    const float dx = fmaf(c.ay1, s1, hy * sb), dy = fmaf(c.ax1, s1, hx * sc);
+                    const float dxs = dx * halfW * c.rt, dys = dy * halfH * c.rt;
+                    const float dt = -(dxs * c.xs + dys * c.ys) * c.rt;
+                    acc[0] += (double)dxs * gx; acc[1] += (double)dxs * gy; acc[2] += (double)dxs;
+                    acc[3] += (double)dys * gx; acc[4] += (double)dys * gy; acc[5] += (double)dys;
+                    acc[6] += (double)dt * gx;  acc[7] += (double)dt * gy;  acc[8] += (double)dt;
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const double tj = wave_sum(acc[j]);
+                    if (lane == j) extra = tj;
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    if (lane < 9) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) t += red[lane + 9 * k];
+        dTheta[(size_t)b * 9 + lane] = (float)(t + extra);
+    }
+}
+
+template <int C, bool PATCH>
+__global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* __restrict__ partial,
+                                                                   float* __restrict__ dTheta, int tiles, int B,
+                                                                   PatchFinish pf, const float* __restrict__ stats,
+                                                                   const float* __restrict__ dLoss, size_t n) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if constexpr (PATCH) { if (pf.ls.kind >= 0) pf.ls.lc = loss_coef(pf.ls.kind, stats, dLoss ? dLoss[0] : 1.0f, n); }
+    if (b < B) finish_image<C, PATCH, false>(partial, dTheta, tiles, b, pf, red[wave], lane);
+}
+
 template <int C, bool WANT_DU, bool SMALL, bool PATCH = false>
 __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
         const float* __restrict__ U, const float* __restrict__ theta, const float* __restrict__ dOut,
@@ -441,7 +569,9 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
     unsigned v = xcd_remap(blockIdx.x, nblk);
     int b, ty, tx;
     int px0 = 0, py0 = 0;                                                // PATCH: top-left pixel of the patch rectangle
+    LossSrc ls{-1, nullptr, nullptr, LossCoef{0.f, 0.f, 0.f}};
     if constexpr (PATCH) {
+        if (pa.kind >= 0) ls = LossSrc{pa.kind, pa.pred, pa.target, loss_coef(pa.kind, pa.stats, pa.dLoss ? pa.dLoss[0] : 1.0f, pa.n)};   // uniform
         const int per = pa.nrx * pa.nry;
         b = v / per;
         const int r = v - b * per, j = r / pa.nrx, i = r - j * pa.nrx;
@@ -497,7 +627,7 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                 float gv = 0.f;
                 if (u >= 0 && u < pa.P && v >= 0 && v < pa.P && col < ow && row < oh) {
                     const size_t e = (size_t)b * pa.PP + (size_t)(v * pa.P + u);
-                    if (pa.idx[e] == row * W + col) { gv = dOut[e] / (float)C; ++nconf; }
+                    if (pa.idx[e] == row * W + col) { gv = patch_grad(ls, dOut, e) / (float)C; ++nconf; }
                 }
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) G[k].v[ch] = gv;
@@ -660,10 +790,30 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < NWAVE * 4; ++k) t += rr[k];
-        partial[(size_t)v * 9 + threadIdx.x] = t;
+        if (pa.ticket) publish_f32(partial + (size_t)v * 9 + threadIdx.x, t);
+        else partial[(size_t)v * 9 + threadIdx.x] = t;
     }
     if constexpr (PATCH) {
-        if (threadIdx.x == 0) pa.confirmed[v] = (redc[0] + redc[1]) + (redc[2] + redc[3]);
+        if (threadIdx.x == 0) {
+            const int nc = (redc[0] + redc[1]) + (redc[2] + redc[3]);
+            if (pa.ticket) publish_i32(pa.confirmed + v, nc); else pa.confirmed[v] = nc;
+        }
+    }
+    // The block that completes image b reduces its tiles itself (finish_image, same code and order as the stand-alone
+    // finish kernel -> same bits) instead of leaving that to a second, launch-latency-bound kernel.
+    if (pa.ticket) {                                                     // uniform
+        __shared__ int last_flag;
+        __shared__ double fred[64];
+        int target = tiles;
+        if constexpr (PATCH) {
+            int txlo, txhi, tylo, tyhi;
+            patch_tile_range(px0, py0, pa.P, tiles_x, tiles / tiles_x, TH_B, txlo, txhi, tylo, tyhi);
+            target = (txhi - txlo + 1) * (tyhi - tylo + 1);
+        }
+        if (take_last_ticket(pa.ticket + b, target, &last_flag) && wave == 0) {
+            const PatchFinish pf{U, theta, dOut, pa.idx, pa.confirmed, pa.P, pa.PP, H, W, sx, sy, tiles_x, ls};
+            finish_image<C, PATCH, true>(partial, pa.dTheta, tiles, b, pf, fred, lane);
+        }
     }
 }
 
@@ -687,116 +837,6 @@ __global__ __launch_bounds__(256) void warp_forward_literal_kernel(const float* 
     for (int c = 0; c < C; ++c)
         Ob[c] = blend(s, Ub[((size_t)s.y0 * W + s.x0) * C + c], Ub[((size_t)s.y1 * W + s.x0) * C + c],
                       Ub[((size_t)s.y0 * W + s.x1) * C + c], Ub[((size_t)s.y1 * W + s.x1) * C + c]);
-}
-
-// Deterministic finish: dTheta[b][j] = sum over the image's tiles, accumulated in f64, fixed order.
-// One wave per image.  The image's partials are `tiles*9` contiguous floats; lane l < 63 walks them
-// with stride 63 (= 7*9), so its accumulator index j = l % 9 never changes and every load instruction
-// is coalesced and independent of the others; the 7 lanes that share a j then meet in LDS.
-// PATCH mode adds the entries the bandwidth kernel could not take (not at their rectangle position): if the image's
-// confirmed count falls short of PP, the wave walks the PP entries and samples the stray ones itself (literal path C
-// arithmetic, f64 accumulation, fixed order).  For the dataloader's rectangles nothing is added.
-struct PatchFinish { const float* U; const float* theta; const float* dPred; const int* idx; const int* confirmed;
-                     int P, PP, H, W; float sx, sy; int tiles_x; };
-template <int C, bool PATCH>
-__global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* __restrict__ partial,
-                                                                   float* __restrict__ dTheta, int tiles, int B,
-                                                                   PatchFinish pf) {
-    __shared__ double red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * 4 + wave;
-    double a = 0.0;
-    int txlo = 0, txhi = -1, tylo = 0, tyhi = -1;                        // PATCH: the tiles the bandwidth kernel wrote
-    if constexpr (PATCH) {
-        if (b < B && pf.P > 0) {
-            const int o = pf.idx[(size_t)b * pf.PP];
-            patch_tile_range(o - (o / pf.W) * pf.W, o / pf.W, pf.P, pf.tiles_x, tiles / pf.tiles_x, TH_B, txlo, txhi, tylo, tyhi);
-        }
-    }
-    auto written = [&](int tile) {                                       // every other partial counts as 0 (and is never read)
-        if constexpr (!PATCH) return true;
-        const int ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
-        return tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi;
-    };
-    if (b < B && lane < 63) {
-        const float* p = partial + (size_t)b * tiles * 9;
-        const int n = tiles * 9;
-        if constexpr (PATCH) {
-            // e advances by 63 = 7 tiles: walk (tx, ty) incrementally instead of dividing per element
-            int tile = lane / 9, ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
-            for (int e = lane; e < n; e += 63) {
-                if (tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi) a += (double)p[e];
-                tx += 7;
-                while (tx >= pf.tiles_x) { tx -= pf.tiles_x; ++ty; }
-            }
-        } else {
-#pragma unroll 4
-            for (int e = lane; e < n; e += 63) a += (double)p[e];
-        }
-    }
-    red[wave][lane] = a;
-    double extra = 0.0;                                                  // lane j < 9: stray entries' share of sum j
-    if constexpr (PATCH) {
-        if (b < B) {                                                     // wave-uniform
-            int cnt = 0;
-            for (int e = lane; e < tiles; e += 64) cnt += written(e) ? pf.confirmed[(size_t)b * tiles + e] : 0;
-            cnt = (int)wave_sum((double)cnt);
-            if (cnt != pf.PP) {
-                const int H = pf.H, W = pf.W, P = pf.P, PP = pf.PP;
-                const int* idx = pf.idx + (size_t)b * PP;
-                const int o = idx[0];
-                const int y0 = o / W, x0 = o - y0 * W;
-                const Theta th = load_theta(pf.theta, b);
-                const SrcGeom g = make_geom<C>(W, H);
-                const float* Ub = pf.U + (size_t)b * H * W * C;
-                const float halfW = (float)W * 0.5f, halfH = (float)H * 0.5f;
-                double acc[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) acc[j] = 0.0;
-                for (int e = lane; e < PP; e += 64) {
-                    const int t = idx[e];
-                    bool direct = false;
-                    if (P > 0) {
-                        const int v = e / P, u = e - v * P;
-                        direct = (x0 + u < W) && (y0 + v < H) && t == (y0 + v) * W + (x0 + u);
-                    }
-                    if (direct) continue;
-                    const int row = t / W, col = t - row * W;
-                    const float gx = lin_at(pf.sx, col), gy = lin_at(pf.sy, row);
-                    const Coord c = make_coord(th, th.a[0] * gx, th.a[3] * gx, th.a[6] * gx, gy, g);
-                    const float gv = pf.dPred[(size_t)b * PP + e] / (float)C;
-                    const size_t ia = ((size_t)c.y0f * W + (size_t)c.x0f) * C, ib = ((size_t)c.y1f * W + (size_t)c.x0f) * C;
-                    const size_t ic = ((size_t)c.y0f * W + (size_t)c.x1f) * C, id = ((size_t)c.y1f * W + (size_t)c.x1f) * C;
-                    const float hx = c.x1f - c.x0f, hy = c.y1f - c.y0f;
-                    float s1 = 0.f, sb = 0.f, sc = 0.f;
-#pragma unroll
-                    for (int ch = 0; ch < C; ++ch) {
-                        const float Ia = Ub[ia + ch], Ib = Ub[ib + ch], Ic = Ub[ic + ch], Id = Ub[id + ch];
-                        const float ddb = Id - Ib, ddc = Id - Ic, u = (Ic - Ia) - ddb;
-                        s1 = fmaf(gv, u, s1); sb = fmaf(gv, ddb, sb); sc = fmaf(gv, ddc, sc);
-                    }
-                    const float dx = fmaf(c.ay1, s1, hy * sb), dy = fmaf(c.ax1, s1, hx * sc);
-                    const float dxs = dx * halfW * c.rt, dys = dy * halfH * c.rt;
-                    const float dt = -(dxs * c.xs + dys * c.ys) * c.rt;
-                    acc[0] += (double)dxs * gx; acc[1] += (double)dxs * gy; acc[2] += (double)dxs;
-                    acc[3] += (double)dys * gx; acc[4] += (double)dys * gy; acc[5] += (double)dys;
-                    acc[6] += (double)dt * gx;  acc[7] += (double)dt * gy;  acc[8] += (double)dt;
-                }
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const double tj = wave_sum(acc[j]);
-                    if (lane == j) extra = tj;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (b < B && lane < 9) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) t += red[wave][lane + 9 * k];
-        dTheta[(size_t)b * 9 + lane] = (float)(t + extra);
-    }
 }
 
 }  // namespace uh
@@ -854,13 +894,13 @@ extern "C" size_t uh_warp_backward_workspace_bytes(int B, int H, int W, int C, i
 
 template <int C>
 static void launch_bwd(const float* U, const float* theta, const float* dOut, float* partial, float* dU, int B,
-                       int H, int W, int oh, int ow, hipStream_t s) {
+                       int H, int W, int oh, int ow, hipStream_t s, int* ticket, float* dTheta) {
     const TileGeom g = tile_geom(oh, ow, TH_B);
     const unsigned nblk = (unsigned)B * g.tiles;
     const bool sm = small_image(H, W, C);
 #define UH_BWD(DU, SM) launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, DU, SM, false>, dim3(nblk), dim3(256), s, U, \
                                    theta, dOut, partial, dU, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk, \
-                                   PatchArgs{nullptr, 0, 0, nullptr, 0, 0})
+                                   PatchArgs{nullptr, 0, 0, nullptr, 0, 0, ticket, dTheta, -1, nullptr, nullptr, nullptr, nullptr, 0})
     if (dU) { if (sm) UH_BWD(true, true); else UH_BWD(true, false); }
     else    { if (sm) UH_BWD(false, true); else UH_BWD(false, false); }
 #undef UH_BWD
@@ -878,20 +918,21 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
         if (e != hipSuccess) return (int)e;
     }
     float* partial = (float*)workspace;
+    int* ticket = ticket_slots(B, s);            // one counter per image; NULL (B too large / first call inside a capture): two kernels
     {
         switch (C) {
-            case 1: launch_bwd<1>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
-            case 2: launch_bwd<2>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
-            case 3: launch_bwd<3>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
-            default: launch_bwd<4>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
+            case 1: launch_bwd<1>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
+            case 2: launch_bwd<2>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
+            case 3: launch_bwd<3>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
+            default: launch_bwd<4>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
-    {
+    if (!ticket) {
         const TileGeom g = tile_geom(oh, ow, TH_B);
         launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel<1, false>, dim3((B + 3) / 4), dim3(256), s,
-                     (const float*)partial, dTheta, g.tiles, B, PatchFinish{});
+                     (const float*)partial, dTheta, g.tiles, B, PatchFinish{}, (const float*)nullptr, (const float*)nullptr, (size_t)0);
     }
     return (int)hipGetLastError();
 }
@@ -903,30 +944,35 @@ extern "C" size_t uh_warp_patch_backward_workspace_bytes(int B, int H, int W, in
     return (size_t)B * g.tiles * (9 * sizeof(float) + sizeof(int));
 }
 
+// `src` says where the patch gradient comes from (dPred, or a point-wise loss formed on the fly)
+struct PatchGradSrc { int kind; const float* dPred; const float* pred; const float* target; const float* stats; const float* dLoss; };
 template <int C>
-static void launch_patch_bwd(const float* U, const float* theta, const float* dPred, const int* idx, float* partial,
+static void launch_patch_bwd(const float* U, const float* theta, const PatchGradSrc& src, const int* idx, float* partial,
                              int* confirmed, float* dTheta, int B, int H, int W, int P, int PP, hipStream_t s) {
     const TileGeom g = tile_geom(H, W, TH_B);
     // block tiles a P x P rectangle can touch: one more than it spans when aligned
     const int nrx = P > 0 ? std::min(g.tiles_x, (P - 1) / (NWAVE * TW) + 2) : 1;
     const int nry = P > 0 ? std::min(g.tiles_y, (P - 1) / TH_B + 2) : 1;
     const unsigned nblk = (unsigned)B * nrx * nry;
-    const PatchArgs pa{idx, P, PP, confirmed, nrx, nry};
+    const size_t n = (size_t)B * PP;
+    // P == 0 (no rectangle): no block tile is launched per image, the finish kernel does all the work
+    int* ticket = P > 0 ? ticket_slots(B, s) : nullptr;
+    const PatchArgs pa{idx, P, PP, confirmed, nrx, nry, ticket, dTheta, src.kind, src.pred, src.target, src.stats, src.dLoss, n};
     if (small_image(H, W, C))
-        launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, true, true>, dim3(nblk), dim3(256), s, U, theta, dPred,
+        launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, true, true>, dim3(nblk), dim3(256), s, U, theta, src.dPred,
                      partial, (float*)nullptr, H, W, H, W, lin_step(W), lin_step(H), g.tiles_x, g.tiles, nblk, pa);
     else
-        launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, false, true>, dim3(nblk), dim3(256), s, U, theta, dPred,
+        launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, false, true>, dim3(nblk), dim3(256), s, U, theta, src.dPred,
                      partial, (float*)nullptr, H, W, H, W, lin_step(W), lin_step(H), g.tiles_x, g.tiles, nblk, pa);
-    const PatchFinish pf{U, theta, dPred, idx, confirmed, P, PP, H, W, lin_step(W), lin_step(H), g.tiles_x};
+    if (ticket) return;
+    const PatchFinish pf{U, theta, src.dPred, idx, confirmed, P, PP, H, W, lin_step(W), lin_step(H), g.tiles_x,
+                         LossSrc{src.kind, src.pred, src.target, LossCoef{0.f, 0.f, 0.f}}};
     launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel<C, true>, dim3((B + 3) / 4), dim3(256), s,
-                 (const float*)partial, dTheta, g.tiles, B, pf);
+                 (const float*)partial, dTheta, g.tiles, B, pf, src.stats, src.dLoss, n);
 }
 
-extern "C" int uh_warp_patch_backward(const float* U, const float* theta, const float* dPred, const int* patch_idx,
-                                      float* dTheta, void* workspace, size_t workspace_bytes, int B, int H, int W, int C,
-                                      int PP, uh_stream_t stream) {
-    if (!U || !theta || !dPred || !patch_idx || !dTheta) return UH_E_NULL;
+static int patch_backward(const float* U, const float* theta, const PatchGradSrc& src, const int* patch_idx, float* dTheta,
+                          void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int PP, uh_stream_t stream) {
     if (int e = check_warp_args(B, H, W, C, H, W)) return e;
     if (PP <= 0) return UH_E_SHAPE;
     if ((uint64_t)B * PP >= (1ull << 31)) return UH_E_TOO_LARGE;
@@ -939,12 +985,32 @@ extern "C" int uh_warp_patch_backward(const float* U, const float* theta, const 
     int* confirmed = (int*)(partial + (size_t)B * g.tiles * 9);
     hipStream_t s = (hipStream_t)stream;
     switch (C) {
-        case 1: launch_patch_bwd<1>(U, theta, dPred, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
-        case 2: launch_patch_bwd<2>(U, theta, dPred, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
-        case 3: launch_patch_bwd<3>(U, theta, dPred, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
-        default: launch_patch_bwd<4>(U, theta, dPred, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
+        case 1: launch_patch_bwd<1>(U, theta, src, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
+        case 2: launch_patch_bwd<2>(U, theta, src, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
+        case 3: launch_patch_bwd<3>(U, theta, src, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
+        default: launch_patch_bwd<4>(U, theta, src, patch_idx, partial, confirmed, dTheta, B, H, W, P, PP, s); break;
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int uh_warp_patch_backward(const float* U, const float* theta, const float* dPred, const int* patch_idx,
+                                      float* dTheta, void* workspace, size_t workspace_bytes, int B, int H, int W, int C,
+                                      int PP, uh_stream_t stream) {
+    if (!U || !theta || !dPred || !patch_idx || !dTheta) return UH_E_NULL;
+    return patch_backward(U, theta, PatchGradSrc{-1, dPred, nullptr, nullptr, nullptr, nullptr}, patch_idx, dTheta, workspace,
+                          workspace_bytes, B, H, W, C, PP, stream);
+}
+
+// d loss / d theta straight from (pred_I2, I2_aug): uh_patch_loss_backward -> uh_warp_patch_backward without the dPred
+// tensor and its launch.  Point-wise kinds only (the SSIM gradient is a 3x3 stencil: it keeps its own kernel).
+extern "C" int uh_warp_patch_loss_backward(int kind, const float* U, const float* theta, const float* pred, const float* target,
+                                           const float* stats16, const float* dLoss, const int* patch_idx, float* dTheta,
+                                           void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int PP,
+                                           uh_stream_t stream) {
+    if (!U || !theta || !pred || !target || !stats16 || !patch_idx || !dTheta) return UH_E_NULL;   // dLoss NULL = 1
+    if (kind != UH_LOSS_REC && kind != UH_LOSS_L1 && kind != UH_LOSS_L1_SMOOTH && kind != UH_LOSS_NCC) return UH_E_SHAPE;
+    return patch_backward(U, theta, PatchGradSrc{kind, nullptr, pred, target, stats16, dLoss}, patch_idx, dTheta, workspace,
+                          workspace_bytes, B, H, W, C, PP, stream);
 }
 
 #ifdef UH_WARP_TRACE

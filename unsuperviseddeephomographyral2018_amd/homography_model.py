@@ -220,14 +220,19 @@ class HomographyModel(object):
                                                              self.patch_indices, P)
             return
         self._l1_fused = None
+        self._mon = None
         if self.fused_patch:
             # the other photometric losses need a global norm before their gradient exists: sample the patch only
             # (no warped frame), let the loss kernels produce dPred, then the sparse warp backward
             self.pred_I2 = ops.warp_patch(self.I, self._theta, self.I2_aug, self.patch_indices, P)
             return
-        # the reference's path: the full warped frame is materialised (:257), then gray + gather (:263-269) -- as ONE
-        # autograd node whose backward is the sparse warp backward (no 79 %-zero gradient frame)
-        self.warped_images, self.pred_I2 = ops.warp_gather(self.I, self._theta, self.patch_indices, P)
+        # the reference's path: the full warped frame is materialised (:257), then gray + gather (:263-269) and the six
+        # loss values (:286-352) -- as ONE autograd node (3 launches forward + backward; the loss gradient and the sparse
+        # warp backward are one kernel, no 79 %-zero gradient frame, no dPred tensor)
+        lt = self.params.loss_type
+        train = lt if (torch.is_grad_enabled() and lt != 'h_loss') else None
+        self.warped_images, self.pred_I2, self._mon = ops.warp_gather_losses(
+            self.I, self._theta, self.patch_indices, P, self.I2_aug, self.pred_h4p, self.gt, train=train)
 
     # ---- homography_model.py:136-166 ----------------------------------------------------------------
     def _L1_smooth_loss(self, x, y):
@@ -272,7 +277,9 @@ class HomographyModel(object):
         # uh_patch_loss_backward (HIP), every other one is a stop_gradient monitor (homography_model.py:286-352).
         grad = torch.is_grad_enabled()
         train = lt if (grad and lt != 'h_loss' and not (lt == 'l1_loss' and self._l1_fused is not None)) else None
-        mon = ops.patch_losses(pred, I2, self.pred_h4p, self.gt, train=train)
+        mon = getattr(self, '_mon', None)           # already produced by transform() on the default path
+        if mon is None:
+            mon = ops.patch_losses(pred, I2, self.pred_h4p, self.gt, train=train)
         self.h_loss, self.rec_loss, self.ssim_loss = mon[5], mon[0], mon[1]
         self.l1_loss, self.l1_smooth_loss, self.ncc_loss = mon[2], mon[3], mon[4]
         if not grad:

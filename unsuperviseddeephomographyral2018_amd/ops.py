@@ -257,6 +257,88 @@ def warp_gather(U, theta, patch_indices, patch_size):
     return _WarpGather.apply(U, theta, patch_indices, patch_size)
 
 
+class _WarpGatherLosses(torch.autograd.Function):
+    """transform() + build_losses() of the reference as ONE autograd node with the fewest launches the un-fused path
+    allows (homography_model.py:257-269, 286-352): forward = uh_warp_forward (the full `warped` frame, as the reference
+    materialises it) + uh_gather_patch_losses_forward (gray + gather + all six loss values; its finish runs in the last
+    block); backward = uh_warp_patch_loss_backward (the loss gradient is formed inside the sparse warp backward, whose
+    finish also runs in the last block).  Same values, bit for bit, as warp_gather -> patch_losses (tests/test_gpu_parity)
+    in 2 + 1 launches instead of 4 + 3.  SSIM's gradient is a stencil: it keeps uh_patch_loss_backward."""
+
+    @staticmethod
+    def forward(ctx, U, theta, patch_idx, patch_size, target, h4p, gt, kind):
+        lib = _lib.load()
+        U = _f32(U, 'U'); theta9 = _f32(theta, 'theta').reshape(-1, 9)
+        target = _f32(target, 'target')
+        B, H, W, Cc = U.shape
+        P = int(patch_size)
+        if patch_idx.dtype != torch.int32 or not patch_idx.is_cuda:
+            raise _lib.UHError('patch_indices must be an int32 tensor on the HIP device')
+        idx = patch_idx.contiguous().reshape(B, -1)
+        if idx.shape[1] != P * P or target.numel() != B * P * P:
+            raise _lib.UHError('patch_indices / target must hold B x P*P entries')
+        warped = torch.empty((B, H, W, Cc), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_warp_forward(_ptr(U), _ptr(theta9), _ptr(warped), None, B, H, W, Cc, H, W, _stream()),
+                   'uh_warp_forward')
+        pred = torch.empty((B, P, P, 1), dtype=torch.float32, device=U.device)
+        out = torch.empty((16,), dtype=torch.float32, device=U.device)
+        nbytes = lib.uh_patch_losses_workspace_bytes(B, P)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=U.device)
+        _lib.check(lib.uh_gather_patch_losses_forward(_ptr(warped), _ptr(idx), _ptr(target), _ptr(h4p), _ptr(gt), _ptr(pred),
+                                                      _ptr(out), _ptr(ws), nbytes, B, H, W, Cc, P, _stream()),
+                   'uh_gather_patch_losses_forward')
+        ctx.kind = kind
+        ctx.dims = (B, H, W, Cc, P)
+        ctx.theta_shape = theta.shape
+        if kind >= 0:
+            ctx.save_for_backward(U, theta9, idx, pred, target, out)
+        ctx.mark_non_differentiable(warped, pred)
+        return warped, pred, out[:6]
+
+    @staticmethod
+    def backward(ctx, dWarped, dPred, dOut):
+        none = (None,) * 8
+        if ctx.kind < 0 or not ctx.needs_input_grad[1]:
+            return none
+        lib = _lib.load()
+        U, theta9, idx, pred, target, stats = ctx.saved_tensors
+        B, H, W, Cc, P = ctx.dims
+        g = _f32(dOut[ctx.kind:ctx.kind + 1], 'dLoss')
+        dT = torch.empty((B, 9), dtype=torch.float32, device=U.device)
+        nbytes = lib.uh_warp_patch_backward_workspace_bytes(B, H, W, Cc)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=U.device)
+        if ctx.kind == _lib.LOSS_KINDS['ssim_loss']:
+            dP = torch.empty_like(pred)
+            _lib.check(lib.uh_patch_loss_backward(ctx.kind, _ptr(pred), _ptr(target), _ptr(stats), _ptr(g), _ptr(dP), B, P,
+                                                  _stream()), 'uh_patch_loss_backward')
+            _lib.check(lib.uh_warp_patch_backward(_ptr(U), _ptr(theta9), _ptr(dP), _ptr(idx), _ptr(dT), _ptr(ws), nbytes,
+                                                  B, H, W, Cc, P * P, _stream()), 'uh_warp_patch_backward')
+        else:
+            _lib.check(lib.uh_warp_patch_loss_backward(ctx.kind, _ptr(U), _ptr(theta9), _ptr(pred), _ptr(target), _ptr(stats),
+                                                       _ptr(g), _ptr(idx), _ptr(dT), _ptr(ws), nbytes, B, H, W, Cc, P * P,
+                                                       _stream()), 'uh_warp_patch_loss_backward')
+        return (None, dT.reshape(ctx.theta_shape)) + (None,) * 6
+
+
+def warp_gather_losses(U, theta, patch_indices, patch_size, target, h4p=None, gt=None, train=None):
+    """-> (warped [B,H,W,C], pred_I2 [B,P,P,1], losses [6] = rec, ssim, l1, l1_smooth, ncc, h_loss).  `train` names the
+    loss being trained on: that element carries d/d theta; warped, pred_I2 and the other five are stop_gradient values
+    (use warp_gather + patch_losses when a gradient through pred_I2 itself is needed)."""
+    B = U.shape[0]
+    if h4p is not None:
+        h4p = _f32(h4p.detach(), 'h4p').reshape(-1); gt = _f32(gt.detach(), 'gt').reshape(-1)
+        if h4p.numel() != B * 8 or gt.numel() != B * 8:
+            raise _lib.UHError('h4p and gt must be [B,8]')
+    kind = -1
+    if train is not None:
+        if train not in _lib.LOSS_KINDS:
+            raise _lib.UHError('warp_gather_losses: no gradient kernel for %r' % (train,))
+        kind = _lib.LOSS_KINDS[train]
+    if kind < 0:
+        theta = theta.detach()
+    return _WarpGatherLosses.apply(U, theta, patch_indices, patch_size, target.detach(), h4p, gt, kind)
+
+
 def gray_patch_gather(warped, patch_indices, patch_size):
     """reduce_mean(axis=3) + flat gather (homography_model.py:263-269) -> [B,P,P,1]."""
     return _GrayPatch.apply(warped, patch_indices, patch_size)
