@@ -4,7 +4,7 @@
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 TAG=${1:-r02}
 COMMIT=${2:-unknown}
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/${TAG}_pytest.log
+timeout 900 python -m pytest tests -m gpu -q --tb=short > gpurun_out/${TAG}_pytest_full.log 2>&1; tail -5 gpurun_out/${TAG}_pytest_full.log > gpurun_out/${TAG}_pytest.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1
 timeout 900 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
 timeout 400 python bench.py --cpu_baseline 0 --north_star 0 --config4 0 --fused_patch 1 > gpurun_out/${TAG}_bench_line_fused_patch.json 2>/dev/null

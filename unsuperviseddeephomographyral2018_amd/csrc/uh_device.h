@@ -346,7 +346,7 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // coherence between them for ordinary accesses, so
 //   * partials are published with agent-scope atomic EXCHANGES (performed at the memory side, past the L2s; a returned
 //     value means the write is done) -- not plain stores + __threadfence(), whose release would write back the whole L2;
-//   * the finishing block reads them with agent-scope atomic loads (sc1: they do not hit a stale line of its own L2);
+//   * the finishing block reads them with sc1 loads (agent scope: they do not hit a stale line of its own L2);
 //   * the counter is an agent-scope atomic add; the last block resets it to 0, so a counter is 0 between launches.
 // The counters live in a library-owned pool (uh::ticket_slots, uh_misc.hip).
 __device__ __forceinline__ void publish_i32(int* p, int v) {
@@ -354,16 +354,34 @@ __device__ __forceinline__ void publish_i32(int* p, int v) {
     asm volatile("" :: "v"(old));                             // ask for the returned value: its arrival = the exchange is done
 }
 __device__ __forceinline__ void publish_f32(float* p, float v) { publish_i32((int*)p, __float_as_int(v)); }
+// Reader of published partials.  COHERENT = true: buffer loads with the sc1 bit (agent scope, what an agent-scope atomic
+// load compiles to) -- but as ORDINARY loads, so that the compiler keeps many of them in flight; a loop of atomic loads
+// issues one at a time and costs a full memory latency per element (measured: 8 us for a 675-float finish).  They cannot
+// move above take_last_ticket()'s barrier, which is all the ordering the pattern needs.
 template <bool COHERENT>
-__device__ __forceinline__ float read_f32(const float* p) {
-    if constexpr (COHERENT) return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else return *p;
-}
-template <bool COHERENT>
-__device__ __forceinline__ int read_i32(const int* p) {
-    if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
+struct PartialReader {
+    __amdgpu_buffer_rsrc_t r;
+    const void* base;
+    __device__ __forceinline__ PartialReader(const void* p, unsigned bytes) : r(make_rsrc(p, bytes)), base(p) {}
+    __device__ __forceinline__ float f32(unsigned i) const {
+        if constexpr (COHERENT) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, i * 4u, 0, /*sc1*/ 16));
+        else return ((const float*)base)[i];
+    }
+    // element i if `ok`, else 0 -- without a branch, so that a batch of them stays in flight together
+    __device__ __forceinline__ float f32_if(bool ok, unsigned i) const {
+        if constexpr (COHERENT)       // an offset past num_records reads as 0
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? i * 4u : 0xfffffff0u, 0, /*sc1*/ 16));
+        else { const float t = ((const float*)base)[ok ? i : 0u]; return ok ? t : 0.f; }
+    }
+    __device__ __forceinline__ int i32_if(bool ok, unsigned i) const {
+        if constexpr (COHERENT) return (int)__builtin_amdgcn_raw_buffer_load_b32(r, ok ? i * 4u : 0xfffffff0u, 0, /*sc1*/ 16);
+        else { const int t = ((const int*)base)[ok ? i : 0u]; return ok ? t : 0; }
+    }
+    __device__ __forceinline__ int i32(unsigned i) const {
+        if constexpr (COHERENT) return (int)__builtin_amdgcn_raw_buffer_load_b32(r, i * 4u, 0, /*sc1*/ 16);
+        else return ((const int*)base)[i];
+    }
+};
 // Whole block calls it after its publish_*() calls; true (in every thread) in the block that took ticket `target - 1`.
 __device__ __forceinline__ bool take_last_ticket(int* ticket, int target, int* lds_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's exchanges have returned = are performed

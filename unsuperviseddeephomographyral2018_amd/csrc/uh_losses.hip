@@ -32,9 +32,17 @@ __device__ __forceinline__ void patch_losses_finish(const float* __restrict__ pa
     double a[NLS + 1];
 #pragma unroll
     for (int k = 0; k <= NLS; ++k) a[k] = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) {
+    const PartialReader<COHERENT> rp(partial, (unsigned)(nblk * NLS * 4));
+    for (int i0 = threadIdx.x; i0 < nblk; i0 += 256 * 4) {          // 4 rows x 7 loads in flight, added in row order
+        float v[4][NLS];
 #pragma unroll
-        for (int k = 0; k < NLS; ++k) a[k] += (double)read_f32<COHERENT>(partial + (size_t)i * NLS + k);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < NLS; ++k) v[q][k] = rp.f32_if(i0 + 256 * q < nblk, (unsigned)((i0 + 256 * q) * NLS + k));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < NLS; ++k) a[k] += (double)v[q][k];
     }
     if (f.h4p) for (int i = threadIdx.x; i < f.nh; i += 256) { const double d = (double)f.h4p[i] - (double)f.gt[i]; a[NLS] += d * d; }
 #pragma unroll

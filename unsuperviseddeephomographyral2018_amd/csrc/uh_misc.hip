@@ -91,7 +91,8 @@ template <bool COHERENT>
 __device__ __forceinline__ void l1_finish(const float* __restrict__ partial, float* __restrict__ loss, int nblk, double inv_n,
                                           int lane) {
     double acc = 0.0;
-    for (int i = lane; i < nblk; i += 64) acc += (double)read_f32<COHERENT>(partial + i);
+    const PartialReader<COHERENT> rp(partial, (unsigned)(nblk * 4));
+    for (int i = lane; i < nblk; i += 64) acc += (double)rp.f32((unsigned)i);
     acc = wave_sum(acc);
     if (lane == 0) loss[0] = (float)(acc * inv_n);
 }
@@ -193,7 +194,10 @@ int* ticket_slots(int n, hipStream_t s) {
         if (st != hipStreamCaptureStatusNone) return nullptr;          // cannot allocate inside a capture
         int* p = nullptr;
         if (hipMalloc(&p, TICKET_POOL * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(p, 0, TICKET_POOL * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+        // (synchronous, and waited for: the first user may run on a non-blocking stream that does not order with stream 0)
+        if (hipMemset(p, 0, TICKET_POOL * sizeof(int)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(p); return nullptr;
+        }
         g_tk_pool[dev] = p;
     }
     if (g_tk_cursor[dev] + n > TICKET_POOL) g_tk_cursor[dev] = 0;

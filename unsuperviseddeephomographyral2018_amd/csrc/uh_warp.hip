@@ -464,20 +464,35 @@ __device__ __forceinline__ void finish_image(const float* __restrict__ partial, 
         const int ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
         return tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi;
     };
+    const PartialReader<COHERENT> rp(partial + (size_t)b * tiles * 9, (unsigned)(tiles * 9 * 4));
+    const PartialReader<COHERENT> rc(pf.confirmed + (size_t)b * tiles, (unsigned)(tiles * 4));
     if (lane < 63) {
-        const float* p = partial + (size_t)b * tiles * 9;
         const int n = tiles * 9;
+        // batches of FB loads in flight, added in index order (the sums do not depend on FB)
+        constexpr int FB = 8;
         if constexpr (PATCH) {
             // e advances by 63 = 7 tiles: walk (tx, ty) incrementally instead of dividing per element
             int tile = lane / 9, ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
-            for (int e = lane; e < n; e += 63) {
-                if (tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi) a += (double)read_f32<COHERENT>(p + e);
-                tx += 7;
-                while (tx >= pf.tiles_x) { tx -= pf.tiles_x; ++ty; }
+            for (int e0 = lane; e0 < n; e0 += 63 * FB) {
+                float v[FB];
+#pragma unroll
+                for (int q = 0; q < FB; ++q) {
+                    const int e = e0 + 63 * q;
+                    v[q] = rp.f32_if(e < n && tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi, (unsigned)e);
+                    tx += 7;
+                    while (tx >= pf.tiles_x) { tx -= pf.tiles_x; ++ty; }
+                }
+#pragma unroll
+                for (int q = 0; q < FB; ++q) a += (double)v[q];
             }
         } else {
-#pragma unroll 4
-            for (int e = lane; e < n; e += 63) a += (double)read_f32<COHERENT>(p + e);
+            for (int e0 = lane; e0 < n; e0 += 63 * FB) {
+                float v[FB];
+#pragma unroll
+                for (int q = 0; q < FB; ++q) v[q] = rp.f32_if(e0 + 63 * q < n, (unsigned)(e0 + 63 * q));
+#pragma unroll
+                for (int q = 0; q < FB; ++q) a += (double)v[q];
+            }
         }
     }
     red[lane] = a;
@@ -485,7 +500,7 @@ __device__ __forceinline__ void finish_image(const float* __restrict__ partial, 
     if constexpr (PATCH) {
         {
             int cnt = 0;
-            for (int e = lane; e < tiles; e += 64) cnt += written(e) ? read_i32<COHERENT>(pf.confirmed + (size_t)b * tiles + e) : 0;
+            for (int e = lane; e < tiles; e += 64) cnt += rc.i32_if(written(e), (unsigned)e);
             cnt = (int)wave_sum((double)cnt);
             if (cnt != pf.PP) {
                 const int H = pf.H, W = pf.W, P = pf.P, PP = pf.PP;
