@@ -342,10 +342,9 @@ def test_launch_profiler_reports_kernel_durations(ops, dev):
         prof = _lib.profile_read()
     finally:
         _lib.profile_enable(False)
-    for k in ('warp_forward', 'warp_backward'):
+    for k in ('warp_forward', 'warp_backward', 'warp_backward_finish'):
         ms, n = prof[k]
         assert n == 3 and 0.0 < ms / n < 5.0, (k, ms, n)
-    assert prof['warp_backward_finish'][1] == 0        # folded into the backward kernel's last block (ticket route)
 
 
 # ---------------------------------------------------------------------------------------------- warp bwd
@@ -667,12 +666,15 @@ def test_warp_patch_loss_backward_equals_two_launch_chain(ops, dev, case, kind):
                                            C, PP, st) == -1
 
 
-def test_last_block_ticket_and_finish_kernel_routes_agree(ops, dev):
-    """The finish of the warp backward (dense and sparse) runs in the last block of each image when a ticket range is
-    available (B <= 4096) and as a second kernel otherwise.  A batch of 4100 small images takes the second route, its
-    two halves take the first: same bits.  Repeating a launch 40 times gives the same bits every time (the last block
-    leaves the counters at 0), also when launches of different batch sizes interleave."""
+def test_last_block_ticket_and_finish_kernel_routes_agree(ops, dev, monkeypatch):
+    """With UH_TICKETS=1 the finish of the warp backward (dense and sparse), of the loss statistics and of l1 runs in the
+    block that takes the last ticket (when a counter range is available: B <= 4096) instead of a second kernel, which is
+    the default route.  Same bits either way: default route vs ticket route on the same inputs; a batch of 4100 small
+    images (two kernels even with tickets on) vs its two halves (ticket route); 40 repeats of one launch (the last block
+    leaves the counters at 0), also when launches of other batch sizes interleave; the launch profiler sees no finish
+    kernel on the ticket route."""
     _lib, lib, p, st = _abi(dev)
+    monkeypatch.setenv('UH_TICKETS', '1')
     rs = np.random.RandomState(5)
     B, H, W, C, P = 4100, 16, 64, 3, 8
     PP = P * P
@@ -699,6 +701,16 @@ def test_last_block_ticket_and_finish_kernel_routes_agree(ops, dev):
         return dT
 
     for f in (sparse, dense):
+        monkeypatch.setenv('UH_TICKETS', '0')
+        default_route = f(0, 300)
+        monkeypatch.setenv('UH_TICKETS', '1')
+        _lib.profile_enable(True)
+        ticket_route = f(0, 300)
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+        assert torch.equal(default_route, ticket_route), f.__name__
+        assert prof['warp_backward'][1] == 1 and prof['warp_backward_finish'][1] == 0
         whole = f(0, B)                                              # B > 4096: two kernels
         halves = torch.cat([f(0, 2048), f(2048, B)])                 # each <= 4096: ticket route
         assert torch.equal(whole, halves), f.__name__
@@ -719,6 +731,10 @@ def test_last_block_ticket_and_finish_kernel_routes_agree(ops, dev):
     l1s = [ops.l1_loss(x, y) for _ in range(30)]
     assert all(torch.equal(v, l1s[0]) for v in l1s)
     assert abs(float(l1s[0]) - float(outs[0][2])) < 1e-6
+    monkeypatch.setenv('UH_TICKETS', '0')
+    ws = torch.empty(nb // 4, device=dev); out = torch.empty(16, device=dev)
+    _lib.check(lib.uh_patch_losses_forward(p(x), p(y), None, None, p(out), p(ws), nb, 64, 128, st), 'losses')
+    assert torch.equal(out, outs[0]) and torch.equal(ops.l1_loss(x, y), l1s[0])
 
 
 @pytest.mark.parametrize('kind', ['rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss'])

@@ -395,6 +395,27 @@ __device__ __forceinline__ bool take_last_ticket(int* ticket, int target, int* l
     __syncthreads();
     return *lds_flag != 0;
 }
+// Two-level variant for grids whose blocks would all hit ONE counter (same-address agent-scope atomics are served one
+// after the other, ~20 ns each: 1024 blocks finishing together spent ~20 us queueing on a single ticket).  Blocks count on
+// their group's counter tickets[1 + group]; the block that completes a group counts on tickets[0]; the block that
+// completes tickets[0] is the last of the grid.  Pure counting tree: what the last block then does is unchanged.
+__device__ __forceinline__ bool take_last_ticket2(int* tickets, int group, int group_size, int n_groups, int* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int last = 0;
+        const int old = __hip_atomic_fetch_add(tickets + 1 + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == group_size - 1) {
+            __hip_atomic_store(tickets + 1 + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int og = __hip_atomic_fetch_add(tickets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = og == n_groups - 1;
+            if (last) __hip_atomic_store(tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *lds_flag = last;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
 // LDS hand-over between the lanes of ONE wave (its ds ops execute in order; this only stops the compiler reordering)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -50,7 +50,8 @@ struct ProfScope {
 };
 
 // `n` device ints that are 0 now and 0 again after the kernel that uses them as last-block tickets (uh_device.h,
-// take_last_ticket).  Library-owned pool per device, handed out round-robin: a range can only be handed out twice at
+// take_last_ticket) -- or nullptr = "launch the separate finish kernel", which is the DEFAULT: the ticket route is
+// opt-in (environment UH_TICKETS=1), see uh_misc.hip.  Library-owned pool per device, handed out round-robin: a range can only be handed out twice at
 // once if more than TICKET_POOL / n such launches are in flight on DIFFERENT streams.  nullptr when n is too large or
 // when the pool does not exist yet and `s` is being captured (hipMalloc is not capturable) -- the caller then launches
 // the separate finish kernel instead.

@@ -100,14 +100,30 @@ __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restri
         const int* __restrict__ idx = ga.idx + (size_t)b * n + c0;
         const float* __restrict__ frame = X + (size_t)b * ga.HW * GC;
         float* __restrict__ pred = ga.pred + (size_t)b * n + c0;
-        for (int t = threadIdx.x; t < m; t += 256) {
-            const float* q = frame + (size_t)idx[t] * GC;
-            float s = q[0];
+        // batches of GB pixels per thread: all index loads, then all frame loads, in flight together (one block has only
+        // ~5 pixels per thread, and a rolled loop would pay two memory latencies for each of them)
+        constexpr int GB = 6;
+        for (int t0 = threadIdx.x; t0 < m; t0 += 256 * GB) {
+            int id[GB];
 #pragma unroll
-            for (int c = 1; c < GC; ++c) s = s + q[c];
-            const float v = s / (float)GC;
-            xt[t] = v;
-            if (t < LPT * 256) pred[t] = v;
+            for (int q = 0; q < GB; ++q) id[q] = idx[min(t0 + 256 * q, m - 1)];
+            float g[GB][GC];
+#pragma unroll
+            for (int q = 0; q < GB; ++q)
+#pragma unroll
+                for (int c = 0; c < GC; ++c) g[q][c] = frame[(size_t)id[q] * GC + c];
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                const int t = t0 + 256 * q;
+                float s = g[q][0];
+#pragma unroll
+                for (int c = 1; c < GC; ++c) s = s + g[q][c];
+                const float v = s / (float)GC;
+                if (t < m) {
+                    xt[t] = v;
+                    if (t < LPT * 256) pred[t] = v;
+                }
+            }
         }
         __syncthreads();
     }
@@ -163,7 +179,9 @@ __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restri
     if (ticket) {
         __shared__ int last_flag;
         __shared__ double fred[NLS + 1][4];
-        if (take_last_ticket(ticket, (int)gridDim.x, &last_flag)) patch_losses_finish<true>(partial, (int)gridDim.x, fin, fred);
+        // counting tree: the image's blocks, then the images (one counter for all 1024 blocks serialises them)
+        if (take_last_ticket2(ticket, b, blocks_per_image, (int)gridDim.x / blocks_per_image, &last_flag))
+            patch_losses_finish<true>(partial, (int)gridDim.x, fin, fred);
     }
 }
 
@@ -294,7 +312,7 @@ static int launch_losses(const float* X, const float* target, const float* h4p, 
                          int B, int P, hipStream_t s, int GC, GatherArgs ga, float* l1_out = nullptr) {
     const int bpi = (P * P + 256 * LPT - 1) / (256 * LPT);
     const LossFinish fin{h4p, gt, B * 8, out16, 1.0 / ((double)B * P * P), 1.0 / ((double)B * (P - 2) * (P - 2)), l1_out};
-    int* ticket = ticket_slots(1, s);            // NULL (first call inside a stream capture): separate finish kernel
+    int* ticket = ticket_slots(1 + B, s);        // NULL (the default, see uh_host.h): separate finish kernel
     const unsigned shm = GC ? (unsigned)((LPT * 256 + 2 * P + 3) * sizeof(float)) : 0u;
 #define UH_LOSSES(GCV) launch_timed_shm(UH_K_LOSSES, patch_losses_kernel<GCV>, dim3((unsigned)B * bpi), dim3(256), shm, s, X, target, \
                                         (float*)workspace, P, bpi, ticket, fin, ga)

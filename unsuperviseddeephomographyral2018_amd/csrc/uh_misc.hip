@@ -9,6 +9,7 @@
 #include "uh_device.h"
 #include "uh_host.h"
 #include <mutex>
+#include <cstdlib>
 #include <vector>
 
 namespace uh {
@@ -115,7 +116,10 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
         if (ticket) publish_f32(partial + blockIdx.x, t); else partial[blockIdx.x] = t;
     }
     if (ticket) {
-        if (take_last_ticket(ticket, (int)gridDim.x, &last_flag) && threadIdx.x < 64)
+        constexpr int GS = 32;                                            // counting tree: groups of 32 blocks (uh_device.h)
+        const int ng = ((int)gridDim.x + GS - 1) / GS, grp = (int)blockIdx.x / GS;
+        const int gsz = min(GS, (int)gridDim.x - grp * GS);
+        if (take_last_ticket2(ticket, grp, gsz, ng, &last_flag) && threadIdx.x < 64)
             l1_finish<true>(partial, loss, (int)gridDim.x, inv_n, (int)threadIdx.x);
     }
 }
@@ -185,6 +189,12 @@ int g_tk_cursor[TK_MAX_DEV];
 }  // namespace
 int* ticket_slots(int n, hipStream_t s) {
     if (n <= 0 || n > TICKET_POOL / 4) return nullptr;
+    // Opt-in (UH_TICKETS=1).  Measured on MI355X (profiles/r02_ticket_ab_step_breakdown.txt): finishing in the last block
+    // costs what the finish kernel costs -- publish, ticket and read-back are three dependent ~2 us round trips to the
+    // memory side -- so the default stays the two-kernel route, which needs no shared counters.  Read per call: the tests
+    // switch it to cover both routes.
+    const char* e = getenv("UH_TICKETS");
+    if (!e || e[0] != '1') return nullptr;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TK_MAX_DEV) { (void)hipGetLastError(); return nullptr; }
     std::lock_guard<std::mutex> lk(g_tk_mu);
@@ -329,7 +339,7 @@ extern "C" int uh_l1_loss_forward(const float* pred, const float* target, float*
     size_t gb = (n + 255) / 256;
     const int nblk = (int)(gb > (size_t)L1_BLOCKS ? (size_t)L1_BLOCKS : gb);
     ProfScope prof(UH_K_L1_FWD, s);
-    int* ticket = ticket_slots(1, s);
+    int* ticket = ticket_slots(1 + (nblk + 31) / 32, s);
     hipLaunchKernelGGL(l1_partial_kernel, dim3(nblk), dim3(256), 0, s, pred, target, (float*)workspace, n, ticket, loss,
                        1.0 / (double)n);
     if (!ticket)

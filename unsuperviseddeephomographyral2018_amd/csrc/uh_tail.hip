@@ -4,8 +4,8 @@
 // i.e. solve_DLT + transform + the l1 branch of build_losses and TF's backward of them
 // (/root/reference/code/homography_model.py:169-269, 321-330).  Because the loss is a scalar and the chain is
 // evaluated at dLoss = 1, the backward does not have to wait for autograd: the caller scales dh4p by the incoming
-// gradient.  The 5 kernels of the un-fused chain (DLT, warp, gather+losses, loss-gradient+warp
-// backward, DLT backward; 4 kernels with the fused patch kernel) are stream-captured once per distinct argument set and
+// gradient.  The 7 kernels of the un-fused chain (DLT, warp, gather+losses and its finish, loss-gradient+warp backward
+// and its finish, DLT backward; 4 kernels with the fused patch kernel) are stream-captured once per distinct argument set and
 // replayed with hipGraphLaunch: one host call and one launch per step, and no inter-kernel launch gaps on the stream.
 #include "uh_device.h"
 #include "uh_host.h"
@@ -90,7 +90,7 @@ static int enqueue_chain(const uh_tail_plan* p, const float* pts1, const float* 
         float* warped = (float*)(ws + p->off_warped);
         float* stats = (float*)(ws + p->off_stats);
         if ((e = uh_warp_forward(U, theta, warped, nullptr, B, H, W, C, H, W, s))) return e;
-        // gray + gather + all loss values in one launch (its finish runs in the last block and also writes `loss`)
+        // gray + gather + all loss values in one call (the finish stage also writes `loss`)
         if ((e = uh::gather_patch_losses(warped, idx, I2, nullptr, nullptr, pred, stats, loss, ws + p->off_ws_loss,
                                          uh_patch_losses_workspace_bytes(B, P), B, H, W, C, P, s))) return e;
         if (dh4p) {

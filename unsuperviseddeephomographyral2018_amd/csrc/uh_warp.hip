@@ -642,7 +642,9 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                 float gv = 0.f;
                 if (u >= 0 && u < pa.P && v >= 0 && v < pa.P && col < ow && row < oh) {
                     const size_t e = (size_t)b * pa.PP + (size_t)(v * pa.P + u);
-                    if (pa.idx[e] == row * W + col) { gv = patch_grad(ls, dOut, e) / (float)C; ++nconf; }
+                    const int ie = pa.idx[e];
+                    const float ge = patch_grad(ls, dOut, e);            // (loaded alongside idx[e], not after the compare)
+                    if (ie == row * W + col) { gv = ge / (float)C; ++nconf; }
                 }
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) G[k].v[ch] = gv;
@@ -933,7 +935,7 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
         if (e != hipSuccess) return (int)e;
     }
     float* partial = (float*)workspace;
-    int* ticket = ticket_slots(B, s);            // one counter per image; NULL (B too large / first call inside a capture): two kernels
+    int* ticket = ticket_slots(B, s);            // one counter per image; NULL (the default, see uh_host.h): two kernels
     {
         switch (C) {
             case 1: launch_bwd<1>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
