@@ -79,9 +79,6 @@ static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the ste
 #define UH_WARP_FWD_MINW 6        // __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow
                                   // (6 x 4 waves x 6 KiB LDS slices = 144 KiB of the CU's 160 KiB; 80 VGPRs, no spill)
 #endif
-#ifndef UH_WARP_BWD_DIET
-#define UH_WARP_BWD_DIET 0        // 1: keep only (x, y, 1/t, G) per pixel across the tap phase and re-derive xs, ys, gy, floor x, floor y
-#endif                            //    where they are used (+10 VALU per pixel, -5 VGPRs per pixel: the 6-waves-per-SIMD experiment)
 #ifndef UH_WARP_BWD_MINW
 #define UH_WARP_BWD_MINW 5        // 96 VGPRs without path C1 (no spill)
 #endif
@@ -659,14 +656,6 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
             fx[k] = floorf(p[k].x); fy[k] = floorf(p[k].y);
         }
         const Extent e = wave_extent<STEPS_B>(fx, fy, g);
-        // UH_WARP_BWD_DIET: floor x, floor y, gy, xs, ys are re-derived where they are used instead of living in VGPRs across
-        // the tap phase (`opaque` keeps the compiler from recognising -- and keeping -- the values it already had)
-        auto opaque = [](float v) { asm volatile("" : "+v"(v)); return v; };
-        auto FX = [&](int k) { if constexpr (UH_WARP_BWD_DIET != 0) return floorf(opaque(p[k].x)); else return fx[k]; };
-        auto FY = [&](int k) { if constexpr (UH_WARP_BWD_DIET != 0) return floorf(opaque(p[k].y)); else return fy[k]; };
-        auto GY = [&](int k) { if constexpr (UH_WARP_BWD_DIET != 0) return -1.0f + sy * (opaque(rowf0) + (float)(k * WY)); else return gy[k]; };
-        auto XS = [&](int k) { if constexpr (UH_WARP_BWD_DIET != 0) return (opaque(A0) + th.a[1] * GY(k)) + th.a[2]; else return p[k].xs; };
-        auto YS = [&](int k) { if constexpr (UH_WARP_BWD_DIET != 0) return (opaque(A3) + th.a[4] * GY(k)) + th.a[5]; else return p[k].ys; };
         // one pixel's contribution to the nine sums
         // hx = x1f - x0f, hy = y1f - y0f (1 for an interior sample, 0 where the clip collapsed the pair).  With
         // ay0 = hy - ay1:  ay1 (Ic-Ia) + ay0 (Id-Ib) = ay1 [(Ic-Ia) - (Id-Ib)] + hy (Id-Ib)  -- the form used here: a
@@ -689,9 +678,9 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
             const float dx = fmaf(ay1, s1, hy * sb), dy = fmaf(ax1, s1, hx * sc);
             const float rt = p[k].rt;
             const float dxs = dx * halfW * rt, dys = dy * halfH * rt;
-            const float dt = -(dxs * XS(k) + dys * YS(k)) * rt;
+            const float dt = -(dxs * p[k].xs + dys * p[k].ys) * rt;
             // gx is the same for the lane's four pixels (one column): the gx-weighted sums are formed once, after the loop
-            const float gyk = GY(k);
+            const float gyk = gy[k];
             acc[1] = fmaf(dxs, gyk, acc[1]); acc[2] += dxs;
             acc[4] = fmaf(dys, gyk, acc[4]); acc[5] += dys;
             acc[7] = fmaf(dt,  gyk, acc[7]); acc[8] += dt;
@@ -716,15 +705,15 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
             if constexpr (STAGE_BWD) st = plan_stage<C, LDSW>(e);
             float ax0[STEPS_B], ay0[STEPS_B];
             auto og = [&](int k) -> unsigned {                          // global offset of tap (y0, x0): paths B and dU only
-                if constexpr (SMALL) return (unsigned)__builtin_fmaf(FY(k), g.rowB, FX(k) * g.pixB);
-                else return (unsigned)FY(k) * (unsigned)g.rowBi + (unsigned)FX(k) * (unsigned)g.pixBi;
+                if constexpr (SMALL) return (unsigned)__builtin_fmaf(fy[k], g.rowB, fx[k] * g.pixB);
+                else return (unsigned)fy[k] * (unsigned)g.rowBi + (unsigned)fx[k] * (unsigned)g.pixBi;
             };
             if (STAGE_BWD && st.fits) {                                 // ---- path A
                 stage_dma<C, LDSW>(rin, lds, lane, e, st, g.rowBi);
                 unsigned oa[STEPS_B];
 #pragma unroll
                 for (int k = 0; k < STEPS_B; ++k) {
-                    const float fxk = FX(k), fyk = FY(k);
+                    const float fxk = fx[k], fyk = fy[k];
                     ax0[k] = p[k].x - fxk; ay0[k] = p[k].y - fyk;
                     oa[k] = (unsigned)__builtin_fmaf(fyk, st.pitch, __builtin_fmaf(fxk, g.pixB, st.nbase));
                 }
@@ -745,7 +734,7 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                         const int k = k0 + j;
                         const unsigned o = og(k);
                         global_quad<C>(rin, o, o + (unsigned)g.rowBi, Ia[j], Ib[j], Ic[j], Id[j]);
-                        ax0[k] = p[k].x - FX(k); ay0[k] = p[k].y - FY(k);
+                        ax0[k] = p[k].x - fx[k]; ay0[k] = p[k].y - fy[k];
                     }
 #pragma unroll
                     for (int j = 0; j < BT_B; ++j) {
