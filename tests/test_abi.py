@@ -24,6 +24,28 @@ def test_header_declares_expected_entry_points():
     assert len(syms) >= 17
 
 
+def test_header_is_plain_c_and_a_c_caller_links(uh_lib_path, tmp_path):
+    """include/uh_hotpath.h is the drop-in boundary for a C caller (cgo / JNI / ctypes ...): it must compile as C99 with
+    gcc -- no C++, no HIP, no torch types -- and a C program that takes the address of every declared entry point must link
+    against the shared library."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    syms = declared_symbols()
+    src = tmp_path / 'caller.c'
+    src.write_text('#include "uh_hotpath.h"\n#include <stdio.h>\ntypedef void (*fn_t)(void);\nint main(void) {\n'
+                   '  fn_t f[] = {%s};\n  printf("%%d %%d\\n", (int)(sizeof f / sizeof f[0]), UH_ABI_VERSION);\n'
+                   '  return f[0] == 0;\n}\n' % ', '.join('(fn_t)%s' % n for n in syms))
+    exe = tmp_path / 'caller'
+    libdir = os.path.dirname(uh_lib_path)
+    r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', '-I', os.path.join(ROOT, 'include'), str(src),
+                        '-L', libdir, '-l:' + os.path.basename(uh_lib_path), '-Wl,-rpath,' + libdir,
+                        '-Wl,--unresolved-symbols=ignore-in-shared-libs', '-o', str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # (not executed: loading libamdhip64 on a GPU-less host is the binding test's business)
+
+
 def test_library_exports_every_declared_symbol(uh_lib_path):
     lib = C.CDLL(uh_lib_path)
     for name in declared_symbols():
