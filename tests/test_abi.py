@@ -132,6 +132,11 @@ def test_product_path_refuses_cpu_tensors(uh_lib_path):
         ops.transformer(U, th, (8, 8))
     with pytest.raises(_lib.UHError, match='no CPU fallback'):
         ops.solve_dlt(torch.zeros(1, 8), torch.zeros(1, 8))
+    idx = torch.zeros(1, 16, dtype=torch.int32)
+    with pytest.raises(_lib.UHError):
+        ops.warp_gather_losses(U, th, idx, 4, torch.zeros(1, 4, 4, 1), train='l1_loss')
+    with pytest.raises(_lib.UHError, match='no gradient kernel'):
+        ops.warp_gather_losses(U, th, idx, 4, torch.zeros(1, 4, 4, 1), train='h_loss')
 
 
 def test_product_package_never_imports_oracle():
