@@ -168,7 +168,6 @@ def warp_point(device, B, H, W, P, rho, iters=20, seed=7):
     torch.cuda.synchronize(device)
     prof = _lib.profile_read()
     _lib.profile_enable(False)
-    # (with UH_TICKETS=1 the finish of the backward runs in the backward kernel itself: no separate launch to time)
     us = {k: (prof[k][0] / prof[k][1] * 1e3 if prof[k][1] else 0.0) for k in ('warp_forward', 'warp_backward', 'warp_backward_finish')}
     nbytes = 4 * B * H * W * 3 * 4
     t_total = (us['warp_forward'] + us['warp_backward'] + us['warp_backward_finish']) * 1e-6

@@ -38,6 +38,16 @@ def relerr(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def assert_same_bits(got, ref, what=''):
+    """"Bit-identical" as DESIGN.md section 4 states it: every element has the same f32 bit pattern, NaN where the
+    reference op order produces NaN (inf - inf in the far field).  +0 / -0 compare equal (the oracle's and the kernel's
+    exact zeros may differ in sign where a weight of -0 meets a 0 pixel)."""
+    got = np.asarray(got); ref = np.asarray(ref)
+    same = (got == ref) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), '%s: %d of %d elements differ, max |diff| %g' % (
+        what, int((~same).sum()), same.size, float(np.nanmax(np.abs(got.astype(np.float64) - ref)[~same])))
+
+
 # ---------------------------------------------------------------------------------------------- DLT
 def test_dlt_forward_vs_oracle(ops, dev, golden):
     d = golden('ref_dlt_system.npz')
@@ -86,8 +96,7 @@ def test_warp_forward_golden_bit_level(ops, dev, golden):
     g = golden('chain_small.npz')
     out, cond = ops.transformer(T(g['I'], dev), T(g['theta32'], dev), (60, 80))
     out = out.cpu().numpy()
-    assert np.abs(out - g['warped32']).max() <= 1e-6
-    assert (out == g['warped32']).mean() > 0.999          # essentially bit-identical
+    assert_same_bits(out, g['warped32'], 'golden chain_small')
     # in-frame pixels vs f64 ground truth
     xs, ys, t, xn, yn, _ = O.sample_coords(g['theta64'], 60, 80, np.float64)
     x = (xn + 1) * 80 / 2; y = (yn + 1) * 60 / 2
@@ -122,7 +131,7 @@ def test_warp_forward_shapes_channels(ops, dev, C, shape):
     theta = (np.tile(np.eye(3), (B, 1, 1)) + 0.15 * rs.randn(B, 3, 3)).astype(np.float32)
     out, cond = ops.transformer(T(U, dev), T(theta, dev), (oh, ow))
     ref, c = O.transformer(U, theta, (oh, ow), np.float32)
-    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-6
+    assert_same_bits(out.cpu().numpy(), ref, 'C=%d %s' % (C, shape))
     assert float(cond) == float(c)
 
 
@@ -138,11 +147,7 @@ def test_warp_forward_degenerate_and_far_field(ops, dev):
     ], np.float32)
     out, cond = ops.transformer(T(U, dev), T(theta, dev), (24, 32))
     ref, c = O.transformer(U, theta, (24, 32), np.float32)
-    o = out.cpu().numpy()
-    assert np.isfinite(o).all() == np.isfinite(ref).all()
-    m = np.isfinite(ref)
-    # far-field weights reach 1e10: compare relative to the magnitude the op order produces
-    assert np.abs(o[m] - ref[m]).max() <= 1e-6 * max(1.0, np.abs(ref[m]).max())
+    assert_same_bits(out.cpu().numpy(), ref, 'degenerate / far field')     # far-field weights reach 1e10, NaN = inf - inf
     assert float(cond) == float(c)
 
 
@@ -176,9 +181,7 @@ def test_warp_forward_staged_and_gather_paths(ops, dev, C):
     ], np.float32)
     out, cond = ops.transformer(T(U, dev), T(theta, dev), (H, W))
     ref, c = O.transformer(U, theta, (H, W), np.float32)
-    o = out.cpu().numpy()
-    assert np.array_equal(o, ref) or np.abs(o - ref).max() <= 1e-6
-    assert (o == ref).mean() > 0.9999
+    assert_same_bits(out.cpu().numpy(), ref, 'staged / gather paths, C=%d' % C)
     assert float(cond) == float(c)
     # and the backward on the same thetas against the f64 closed form evaluated at the f32 sample positions
     # (these "round" thetas put many samples exactly on pixel boundaries, where an f32/f64 floor() flip would
@@ -239,16 +242,10 @@ def test_config4_forward_vs_oracle(ops, dev):
     ref, c = O.transformer(U, theta, (H, W), np.float32)
     out, cond = ops.transformer(T(U, dev), T(theta, dev), (H, W))
     o = out.cpu().numpy()
-    m = np.isfinite(ref)
-    assert np.array_equal(np.isfinite(o), m)
-    assert np.abs(o[m] - ref[m]).max() <= 1e-6 * max(1.0, np.abs(ref[m]).max())
-    assert (o[m] == ref[m]).mean() > 0.9999
+    assert_same_bits(o, ref, 'config 4, lean kernel')
     assert float(cond) == float(c)
     lit = ops.transformer_literal(T(U, dev), T(theta, dev), (H, W)).cpu().numpy()
-    assert np.abs(lit[m] - ref[m]).max() <= 1e-6 * max(1.0, np.abs(ref[m]).max())
-    assert (lit[m] == ref[m]).mean() > 0.9999
-    same = (o == lit) | (np.isnan(o) & np.isnan(lit))
-    assert same.all()
+    assert_same_bits(lit, ref, 'config 4, literal kernel')
     # f64 ground truth where the perspective divide is benign
     w64, _ = O.transformer(U[[0, 2]], theta[[0, 2]].astype(np.float64), (H, W), np.float64)
     xs, ys, t, xn, yn, _ = O.sample_coords(theta[[0, 2]].astype(np.float64), H, W, np.float64)
@@ -262,8 +259,7 @@ def test_literal_kernel_vs_oracle_small(ops, dev, golden):
     full size carries weight."""
     g = golden('chain_small.npz')
     lit = ops.transformer_literal(T(g['I'], dev), T(g['theta32'], dev), (60, 80)).cpu().numpy()
-    assert np.abs(lit - g['warped32']).max() <= 1e-6
-    assert (lit == g['warped32']).mean() > 0.999
+    assert_same_bits(lit, g['warped32'], 'literal kernel, golden chain_small')
 
 
 @pytest.mark.parametrize('kind', ['dense', 'patch'])
@@ -327,7 +323,7 @@ def test_warp_forward_large_image_offsets(ops, dev):
     theta = np.array([[[0.9, 0.05, 0.01], [-0.04, 1.1, 0.02], [0.02, -0.03, 1]]], np.float32)
     out, _ = ops.transformer(T(U, dev), T(theta, dev), (64, 96))
     ref, _ = O.transformer(U, theta, (64, 96), np.float32)
-    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-6
+    assert_same_bits(out.cpu().numpy(), ref, 'large image')
 
 
 def test_launch_profiler_reports_kernel_durations(ops, dev):
@@ -468,7 +464,7 @@ def test_gray_patch_backward_index_sets(ops, dev, case):
     kernel pair (dense rectangle write + atomic fix-up of the entries that are not at their rectangle position) must give
     the same frame as a NumPy np.add.at for: the dataloader's rectangle, a rectangle whose rows run past the right edge,
     a rectangle with a few swapped / duplicated entries, fully random indices, and PP that is not a square."""
-    rs = np.random.RandomState(hash(case) % 1000)
+    rs = np.random.RandomState(len(case) * 11)
     B, H, W, C, P = 3, 20, 28, 3, 6
     PP = P * P
     u = np.arange(P)
@@ -498,14 +494,15 @@ def test_gray_patch_backward_index_sets(ops, dev, case):
     assert np.abs(dW.cpu().numpy().reshape(B, H * W, C) - ref).max() <= 1e-6
 
 
+@pytest.mark.parametrize('C', [1, 3, 4])
 @pytest.mark.parametrize('case', ['rect', 'rect_wrapping_row', 'rect_with_swaps_and_dups', 'random', 'non_square'])
-def test_warp_patch_backward_equals_dense_chain(ops, dev, case):
+def test_warp_patch_backward_equals_dense_chain(ops, dev, case, C):
     """uh_warp_patch_backward (sparse: dPred + indices, tiles outside the patch rectangle skipped, stray entries added one
     by one) against the dense chain it replaces, uh_gray_patch_backward -> uh_warp_backward, on the same index sets as
     above: bit-identical on true rectangles, <= 1e-5 relative where stray entries take the f64 fix-up path (a rectangle
     whose rows run past the right edge has stray entries: x0 + u >= W is not a pixel of that row)."""
-    rs = np.random.RandomState(hash(case) % 1000 + 7)
-    B, H, W, C, P = 3, 60, 92, 3, 24
+    rs = np.random.RandomState(len(case) * 37 + C)
+    B, H, W, P = 3, 60, 92, 24
     PP = P * P
     u = np.arange(P)
     x0 = np.array([3, 40, 66]); y0 = np.array([2, 19, 33])
@@ -569,13 +566,18 @@ def test_warp_gather_node_matches_two_node_chain(ops, dev):
     assert torch.equal(t1.grad, t2.grad)
 
 
-# ------------------------------------------------------------------------- folded launches (last-block tickets)
+# ------------------------------------------------------------------------- folded launches
 def _abi(dev):
     from unsuperviseddeephomographyral2018_amd import _lib
     import ctypes as C_
     lib = _lib.load()
     return _lib, lib, (lambda t: None if t is None else C_.c_void_p(t.data_ptr())), \
         C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def C_void(t, skip_elems):
+    import ctypes as C_
+    return C_.c_void_p(t.data_ptr() + 4 * skip_elems)
 
 
 def _patch_case(rs, case, B, H, W, P):
@@ -630,7 +632,7 @@ def test_gather_patch_losses_equals_two_launch_chain(ops, dev, B, H, W, P, case,
 @pytest.mark.parametrize('kind', ['rec_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss'])
 @pytest.mark.parametrize('case', ['rect', 'swaps_and_dups', 'random'])
 def test_warp_patch_loss_backward_equals_two_launch_chain(ops, dev, case, kind):
-    """uh_warp_patch_loss_backward (loss gradient formed inside the sparse warp backward, finish in the last block) against
+    """uh_warp_patch_loss_backward (loss gradient formed inside the sparse warp backward) against
     uh_patch_loss_backward -> uh_warp_patch_backward: bit-identical dTheta for every point-wise loss kind and every index
     set (the stray entries' f64 path forms the same gradient); dLoss = NULL means 1; SSIM is refused."""
     _lib, lib, p, st = _abi(dev)
@@ -666,77 +668,6 @@ def test_warp_patch_loss_backward_equals_two_launch_chain(ops, dev, case, kind):
                                            C, PP, st) == -1
 
 
-def test_last_block_ticket_and_finish_kernel_routes_agree(ops, dev, monkeypatch):
-    """With UH_TICKETS=1 the finish of the warp backward (dense and sparse), of the loss statistics and of l1 runs in the
-    block that takes the last ticket (when a counter range is available: B <= 4096) instead of a second kernel, which is
-    the default route.  Same bits either way: default route vs ticket route on the same inputs; a batch of 4100 small
-    images (two kernels even with tickets on) vs its two halves (ticket route); 40 repeats of one launch (the last block
-    leaves the counters at 0), also when launches of other batch sizes interleave; the launch profiler sees no finish
-    kernel on the ticket route."""
-    _lib, lib, p, st = _abi(dev)
-    monkeypatch.setenv('UH_TICKETS', '1')
-    rs = np.random.RandomState(5)
-    B, H, W, C, P = 4100, 16, 64, 3, 8
-    PP = P * P
-    U = T(rs.randn(B, H, W, C).astype(np.float32), dev)
-    tth = T((np.tile(np.eye(3), (B, 1, 1)) + 0.05 * rs.randn(B, 3, 3)).astype(np.float32).reshape(B, 9), dev)
-    idx = T(_patch_case(rs, 'rect', B, H, W, P), dev)
-    dP = T(rs.randn(B, PP).astype(np.float32), dev)
-    dO = T(rs.randn(B, H, W, C).astype(np.float32), dev)
-
-    def sparse(lo, hi):
-        n = hi - lo
-        nb = lib.uh_warp_patch_backward_workspace_bytes(n, H, W, C); ws = torch.empty(nb // 4, device=dev)
-        dT = torch.empty(n, 9, device=dev)
-        _lib.check(lib.uh_warp_patch_backward(p(U[lo:hi]), p(tth[lo:hi]), p(dP[lo:hi]), p(idx[lo:hi]), p(dT), p(ws), nb, n,
-                                              H, W, C, PP, st), 'patch_bwd')
-        return dT
-
-    def dense(lo, hi):
-        n = hi - lo
-        nb = lib.uh_warp_backward_workspace_bytes(n, H, W, C, H, W); ws = torch.empty(nb // 4, device=dev)
-        dT = torch.empty(n, 9, device=dev)
-        _lib.check(lib.uh_warp_backward(p(U[lo:hi]), p(tth[lo:hi]), p(dO[lo:hi]), p(dT), None, p(ws), nb, n, H, W, C, H, W, st),
-                   'warp_bwd')
-        return dT
-
-    for f in (sparse, dense):
-        monkeypatch.setenv('UH_TICKETS', '0')
-        default_route = f(0, 300)
-        monkeypatch.setenv('UH_TICKETS', '1')
-        _lib.profile_enable(True)
-        ticket_route = f(0, 300)
-        torch.cuda.synchronize()
-        prof = _lib.profile_read()
-        _lib.profile_enable(False)
-        assert torch.equal(default_route, ticket_route), f.__name__
-        assert prof['warp_backward'][1] == 1 and prof['warp_backward_finish'][1] == 0
-        whole = f(0, B)                                              # B > 4096: two kernels
-        halves = torch.cat([f(0, 2048), f(2048, B)])                 # each <= 4096: ticket route
-        assert torch.equal(whole, halves), f.__name__
-        first = f(0, 300)
-        for it in range(40):
-            if it % 3 == 0:
-                f(300, 300 + 17 + it)                                # another batch size in between
-            assert torch.equal(f(0, 300), first), (f.__name__, it)
-    # the loss kernels' ticket: 60 repeats, identical outputs
-    x = T(rs.randn(64, 128, 128).astype(np.float32), dev); y = T(rs.randn(64, 128, 128).astype(np.float32), dev)
-    nb = lib.uh_patch_losses_workspace_bytes(64, 128)
-    outs = []
-    for it in range(60):
-        ws = torch.empty(nb // 4, device=dev); out = torch.empty(16, device=dev)
-        _lib.check(lib.uh_patch_losses_forward(p(x), p(y), None, None, p(out), p(ws), nb, 64, 128, st), 'losses')
-        outs.append(out)
-    assert all(torch.equal(o, outs[0]) for o in outs)
-    l1s = [ops.l1_loss(x, y) for _ in range(30)]
-    assert all(torch.equal(v, l1s[0]) for v in l1s)
-    assert abs(float(l1s[0]) - float(outs[0][2])) < 1e-6
-    monkeypatch.setenv('UH_TICKETS', '0')
-    ws = torch.empty(nb // 4, device=dev); out = torch.empty(16, device=dev)
-    _lib.check(lib.uh_patch_losses_forward(p(x), p(y), None, None, p(out), p(ws), nb, 64, 128, st), 'losses')
-    assert torch.equal(out, outs[0]) and torch.equal(ops.l1_loss(x, y), l1s[0])
-
-
 @pytest.mark.parametrize('kind', ['rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss'])
 def test_warp_gather_losses_node_matches_two_node_chain(ops, dev, kind):
     """ops.warp_gather_losses (transform() + build_losses() as one node: 2 launches forward, 1 backward) against
@@ -763,6 +694,138 @@ def test_warp_gather_losses_node_matches_two_node_chain(ops, dev, kind):
     # train=None: no graph at all
     assert not ops.warp_gather_losses(U, t3, idx, P, I2, h4p, gt)[2].requires_grad
 
+
+
+# ------------------------------------------------------------- images beyond 2^24 bytes (integer-offset instantiations)
+def _large_inputs(B=3, H=1200, W=1200, C=3, seed=5):
+    """One frame of H*W*C*4 = 17.3 MB > 2^24 bytes: offsets are no longer exact in f32, every kernel takes its SMALL=false
+    instantiation (integer offsets: uh_device.h global_offsets<false>, uh_warp.hip og(), uh_patch.hip split_index).
+    Three thetas so that every wave path runs: near-identity (interior, staged), zoom-out x3 (interior, rectangle too
+    large: gather), a frame-crossing shift with perspective (clipped gather)."""
+    rs = np.random.RandomState(seed)
+    U = rs.randn(B, H, W, C).astype(np.float32)
+    theta = np.array([[[0.9, 0.05, 0.01], [-0.04, 1.1, 0.02], [0.02, -0.03, 1]],
+                      [[3.0, 0.1, 0], [-0.1, 3.0, 0], [0, 0, 1]],
+                      [[1, 0, 0.6], [0, 1, -0.5], [0.3, 0.2, 1]]], np.float32)[:B]
+    return rs, U, theta
+
+
+def test_large_image_backward_dense_vs_oracle(ops, dev):
+    """warp_backward_kernel<C, *, SMALL=false>: dTheta (and dU) of a 1200x1200x3 source against the f64 closed form at the
+    f32 sample positions; out_size != (H, W) keeps the oracle fast and covers the backward with a resampled output."""
+    rs, U, theta = _large_inputs()
+    B, H, W, C = U.shape
+    oh, ow = 200, 264
+    g = rs.randn(B, oh, ow, C).astype(np.float32)
+    Ut = T(U, dev).requires_grad_(True); tt = T(theta, dev).requires_grad_(True)
+    out, _ = ops.transformer(Ut, tt, (oh, ow))
+    assert_same_bits(out.detach().cpu().numpy(), O.transformer(U, theta, (oh, ow), np.float32)[0], 'large image forward')
+    out.backward(T(g, dev))
+    dth, dU = O.transformer_backward(U, theta, g, (oh, ow), np.float64, want_dU=True, coord_dtype=np.float32)
+    got = tt.grad.cpu().numpy().reshape(-1, 3, 3)
+    gotU = Ut.grad.cpu().numpy()
+    for k in range(B):
+        assert relerr(got[k], dth[k]) < 1e-4, (k, relerr(got[k], dth[k]))
+        assert np.abs(gotU[k] - dU[k]).max() < 1e-4 * max(np.abs(dU[k]).max(), 1.0), k
+    # and without dU (the instantiation the training path uses)
+    t2 = T(theta, dev).requires_grad_(True)
+    ops.transformer(T(U, dev), t2, (oh, ow))[0].backward(T(g, dev))
+    assert torch.equal(t2.grad, tt.grad)
+
+
+def test_large_image_sparse_backward_and_fused_patch(ops, dev):
+    """The SMALL=false instantiations of the sparse backward (uh_warp_patch_backward) and of the fused patch kernel
+    (uh_warp_patch_l1_fwdbwd) on a 1200x1200x3 frame: sparse == dense chain bit for bit on a rectangle; fused pred ==
+    un-fused pred bit for bit, loss and d/dtheta within 1e-4 / 1e-4 relative."""
+    rs, U, theta = _large_inputs()
+    B, H, W, C = U.shape
+    P = 128
+    PP = P * P
+    x0 = np.array([100, 500, 900]); y0 = np.array([700, 40, 1000])
+    u = np.arange(P)
+    idx = ((u[None, :, None] + y0[:, None, None]) * W + (u[None, None, :] + x0[:, None, None])).reshape(B, PP).astype(np.int32)
+    _lib, lib, p, st = _abi(dev)
+    Ud, tth, tidx = T(U, dev), T(theta.reshape(B, 9), dev), T(idx, dev)
+    dP = T(rs.randn(B, PP).astype(np.float32), dev)
+    dW = torch.empty(B, H, W, C, device=dev)
+    _lib.check(lib.uh_gray_patch_backward(p(dP), p(tidx), p(dW), B, H, W, C, PP, st), 'gray_bwd')
+    nb = lib.uh_warp_backward_workspace_bytes(B, H, W, C, H, W); ws = torch.empty(nb // 4, device=dev)
+    dT_dense = torch.empty(B, 9, device=dev)
+    _lib.check(lib.uh_warp_backward(p(Ud), p(tth), p(dW), p(dT_dense), None, p(ws), nb, B, H, W, C, H, W, st), 'warp_bwd')
+    nb2 = lib.uh_warp_patch_backward_workspace_bytes(B, H, W, C); ws2 = torch.empty(nb2 // 4, device=dev)
+    dT = torch.full((B, 9), 7.0, device=dev)
+    _lib.check(lib.uh_warp_patch_backward(p(Ud), p(tth), p(dP), p(tidx), p(dT), p(ws2), nb2, B, H, W, C, PP, st), 'patch_bwd')
+    assert torch.equal(dT, dT_dense) and float(dT.abs().max()) > 0
+    del dW
+    # fused patch kernel vs the un-fused chain on the same theta
+    I2 = T(rs.randn(B, P, P, 1).astype(np.float32), dev)
+    ta = T(theta, dev).requires_grad_(True); tb = T(theta, dev).requires_grad_(True)
+    warped, _ = ops.transformer(Ud, ta, (H, W))
+    pa = ops.gray_patch_gather(warped, tidx, P)
+    la = ops.l1_loss(pa, I2)
+    lb, pb = ops.warp_patch_l1(Ud, tb, I2, tidx, P)
+    assert torch.equal(pa, pb)
+    assert abs(float(la) - float(lb)) < 1e-6
+    la.backward(); lb.backward()
+    assert relerr(tb.grad.cpu().numpy(), ta.grad.cpu().numpy()) < 1e-4
+    # pred against the oracle on the rows of one image (every pixel of the full frame is the forward test's business)
+    ref = O.transformer(U[:1], theta[:1], (H, W), np.float32)[0]
+    gray = O.gray_patch_gather(ref, idx[:1], P, np.float32)
+    assert_same_bits(pa[:1].detach().cpu().numpy(), gray, 'large image pred_I2')
+
+
+@pytest.mark.parametrize('C', [1, 3])
+@pytest.mark.parametrize('shape', [(3, 20, 30, 41, 70), (2, 64, 64, 16, 200), (2, 97, 45, 130, 33)])
+def test_warp_backward_out_size_differs_from_input(ops, dev, C, shape):
+    """Backward with out_size != (H, W) (ragged, up- and down-sampled): dTheta and dU vs the f64 closed form."""
+    B, H, W, oh, ow = shape
+    rs = np.random.RandomState(C * 100 + H)
+    U = rs.randn(B, H, W, C).astype(np.float32)
+    theta = (np.tile(np.eye(3), (B, 1, 1)) + 0.08 * rs.randn(B, 3, 3)).astype(np.float32)
+    g = rs.randn(B, oh, ow, C).astype(np.float32)
+    Ut = T(U, dev).requires_grad_(True); tt = T(theta, dev).requires_grad_(True)
+    ops.transformer(Ut, tt, (oh, ow))[0].backward(T(g, dev))
+    dth, dU = O.transformer_backward(U, theta, g, (oh, ow), np.float64, want_dU=True, coord_dtype=np.float32)
+    got = tt.grad.cpu().numpy().reshape(-1, 3, 3)
+    for k in range(B):
+        assert relerr(got[k], dth[k]) < 1e-4, (k, relerr(got[k], dth[k]))
+    assert np.abs(Ut.grad.cpu().numpy() - dU).max() < 1e-4 * max(np.abs(dU).max(), 1.0)
+
+
+def test_sparse_backward_tolerates_indices_outside_the_frame(ops, dev):
+    """A negative or >= H*W patch index is not a pixel (tf.gather raises on CPU): the sparse backward and the dense
+    scatter must not write outside their buffers; such entries contribute nothing, the others are unaffected."""
+    rs = np.random.RandomState(3)
+    B, H, W, C, P = 2, 40, 52, 3, 8
+    PP = P * P
+    _lib, lib, p, st = _abi(dev)
+    idx = _patch_case(rs, 'rect', B, H, W, P)
+    bad = idx.copy()
+    bad[0, 0] = -5                    # the ANCHOR of image 0: no rectangle -> every entry of that image is a stray
+    bad[1, 7] = H * W + 3; bad[1, 9] = -1
+    U = T(rs.randn(B, H, W, C).astype(np.float32), dev)
+    tth = T((np.tile(np.eye(3), (B, 1, 1)) + 0.05 * rs.randn(B, 3, 3)).astype(np.float32).reshape(B, 9), dev)
+    dPn = rs.randn(B, PP).astype(np.float32)
+    nb = lib.uh_warp_patch_backward_workspace_bytes(B, H, W, C)
+
+    def run(ix, dp):
+        guard = torch.full((nb // 4 + 64,), 3.0, device=dev)            # canaries either side of the workspace
+        ws = guard[32:32 + nb // 4]
+        dT = torch.empty(B, 9, device=dev)
+        _lib.check(lib.uh_warp_patch_backward(p(U), p(tth), p(T(dp, dev)), p(T(ix, dev)), p(dT), p(ws), nb, B, H, W, C, PP, st), 'pb')
+        torch.cuda.synchronize()
+        assert float(guard[:32].min()) == 3.0 and float(guard[-32:].max()) == 3.0
+        return dT.cpu().numpy()
+    got = run(bad, dPn)
+    dz = dPn.copy(); dz[0, 0] = 0; dz[1, 7] = 0; dz[1, 9] = 0            # the same gradient with the bad entries silenced
+    ref = run(idx, dz)
+    assert np.isfinite(got).all()
+    for k in range(B):
+        assert relerr(got[k], ref[k]) < 1e-5, (k, got[k], ref[k])
+    dW = torch.full((B * H * W * C + 64,), 3.0, device=dev)
+    _lib.check(lib.uh_gray_patch_backward(p(T(dPn, dev)), p(T(bad, dev)), C_void(dW, 32), B, H, W, C, PP, st), 'gray_bwd')
+    torch.cuda.synchronize()
+    assert float(dW[:32].min()) == 3.0 and float(dW[-32:].max()) == 3.0
 
 # ---------------------------------------------------------------------------------------------- chain
 def chain_unfused(ops, I, I2, pts1, h4p, idx, P, W, H, f64=False):
@@ -839,7 +902,7 @@ def test_full_size_properties(ops, dev):
     # (1) oracle on the first two images, every pixel, identical theta
     th_np = theta[:2].cpu().numpy()
     ref, _ = O.transformer(d['I'], th_np, (H, W), np.float32)
-    assert np.abs(out[:2].cpu().numpy() - ref).max() <= 1e-6
+    assert_same_bits(out[:2].cpu().numpy(), ref, 'full size')
     w64, _ = O.transformer(d['I'], th_np.astype(np.float64), (H, W), np.float64)
     xs, ys, t, xn, yn, _ = O.sample_coords(th_np.astype(np.float64), H, W, np.float64)
     x = (xn + 1) * W / 2; y = (yn + 1) * H / 2

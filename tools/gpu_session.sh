@@ -1,0 +1,62 @@
+#!/bin/bash
+# ONE parametrised GPU session script (replaces the per-session gpu_r2*.sh / gpu_final*.sh one-offs).
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh TAG stage [stage ...]'
+# Every stage writes gpurun_out/${TAG}_*; copy what is to be judged into profiles/ by hand.  Stages:
+#   tests[:K]       pytest -m gpu (optionally -k K), full log + tail
+#   smoke           __graft_entry__.smoke()
+#   bench           default bench line (+ fused-patch and raw-regressor lines with bench_extra)
+#   bench_extra     the two extra lines
+#   bench2          python bench.py --gpus 2 on ONE GPU over gloo (functional check of the N > 1 path and the self-launch)
+#   rocprof         rocprofv3 --kernel-trace --stats of the bench command + steady-state step breakdown
+#   rocprof_c4      the same of bench.py --only_points config4 (one shape per kernel name)
+#   traffic         FETCH_SIZE / WRITE_SIZE passes (own runs, --kernel-trace only) -> traffic_${TAG}.json, both shapes
+#   pmc_c4          SQ / LDS / TA / TCP / TCC counter groups at config 4 (tools/gpu_pmc2.sh)
+#   micro:V1,V2     A/B/A/B microbench of the shipped library against lib/variants/libuh_V*.so (tools/variants.sh builds them)
+#   vtests:V[:K]    pytest -m gpu with UH_LIB_PATH = variant V
+#   inputs          section-8 f3 timing (tools/time_inputs.py)
+#   trace:V         per-wave phase trace with the -DUH_WARP_TRACE variant V (tools/trace_waves.py)
+mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
+TAG=$1; shift
+COMMIT=$(cat gpurun_out/.commit 2>/dev/null || echo unknown)
+VDIR=unsuperviseddeephomographyral2018_amd/lib/variants
+MCFG=${MCFG:-"128,240,320,128,45;128,480,640,128,64"}
+BENCH="python /root/repo/bench.py --steps 30 --warmup 5 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0"
+for ST in "$@"; do
+  IFS=: read -r NAME A1 A2 <<< "$ST"
+  echo "== stage $NAME $A1 $A2"
+  case $NAME in
+    tests)  timeout 1200 python -m pytest tests -m gpu -q --tb=short ${A1:+-k "$A1"} > gpurun_out/${TAG}_pytest_full.log 2>&1; tail -5 gpurun_out/${TAG}_pytest_full.log | tee gpurun_out/${TAG}_pytest.log ;;
+    smoke)  timeout 300 python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1; tail -2 gpurun_out/${TAG}_smoke.log ;;
+    bench)  timeout 1200 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err; cut -c1-600 gpurun_out/${TAG}_bench_line.json ;;
+    bench_extra)
+            timeout 400 python bench.py --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --fused_patch 1 > gpurun_out/${TAG}_bench_line_fused_patch.json 2>/dev/null
+            timeout 400 python bench.py --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --mid_training_theta 0 > gpurun_out/${TAG}_bench_line_raw_regressor.json 2>/dev/null ;;
+    bench2) UH_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --cpu_baseline 0 --quality 0 > gpurun_out/${TAG}_bench_line_2ranks_gloo_one_gpu.json 2> gpurun_out/${TAG}_bench_2ranks.err; cut -c1-400 gpurun_out/${TAG}_bench_line_2ranks_gloo_one_gpu.json ;;
+    rocprof)
+            ( cd /tmp && rm -rf /tmp/prof_$TAG && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench --output-format csv -- $BENCH > /root/repo/gpurun_out/${TAG}_bench_line_under_rocprof.json 2>/dev/null )
+            cp $(find /tmp/prof_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_bench_kernel_stats.csv 2>/dev/null
+            python tools/step_breakdown.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 20 60 > gpurun_out/${TAG}_step_breakdown.txt 2>&1 ;;
+    rocprof_c4)
+            ( cd /tmp && rm -rf /tmp/prof4_$TAG && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof4_$TAG -o c4 --output-format csv -- python /root/repo/bench.py --only_points config4 > /root/repo/gpurun_out/${TAG}_config4_point_under_rocprof.json 2>/dev/null )
+            cp $(find /tmp/prof4_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_config4_kernel_stats.csv 2>/dev/null
+            grep -E "warp_(forward|backward)_kernel" gpurun_out/${TAG}_config4_kernel_stats.csv | cut -c1-200 ;;
+    traffic)
+            for W in bench c4; do
+              if [ $W = bench ]; then PC="python /root/repo/bench.py --steps 5 --warmup 3 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0"; DIMS="64 240 320"; else PC="python /root/repo/bench.py --only_points config4"; DIMS="128 480 640"; fi
+              ( cd /tmp && rm -rf /tmp/pmc_$W && mkdir -p /tmp/pmc_$W && i=0 && for C in "FETCH_SIZE" "WRITE_SIZE"; do i=$((i+1)); timeout 400 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$W/p$i -o p --output-format csv -- $PC > /tmp/pmc_$W/log$i.txt 2>&1 || echo "pmc pass $W $i failed"; done )
+              python tools/traffic_from_pmc.py /tmp/pmc_$W $DIMS gpurun_out/traffic_${TAG}.json "$PC" "measured $(date -u +%Y-%m-%d) on one MI355X at commit $COMMIT by tools/gpu_session.sh traffic" > /dev/null
+            done ;;
+    pmc_c4) bash tools/gpu_pmc2.sh 128,480,640,128,64 ${TAG}_c4 > gpurun_out/${TAG}_pmc.log 2>&1 ;;
+    micro)  : > gpurun_out/${TAG}_micro.jsonl
+            for rep in 1 2; do
+              timeout 150 python tools/microbench.py --iters 40 --configs "$MCFG" 2>/dev/null >> gpurun_out/${TAG}_micro.jsonl
+              for V in ${A1//,/ }; do UH_LIB_PATH=$VDIR/libuh_$V.so timeout 150 python tools/microbench.py --iters 40 --configs "$MCFG" 2>/dev/null >> gpurun_out/${TAG}_micro.jsonl; done
+            done
+            python tools/show_micro.py gpurun_out/${TAG}_micro.jsonl 2>/dev/null | tail -40 ;;
+    vtests) UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_model.py -m gpu -q --tb=short -x ${A2:+-k "$A2"} > gpurun_out/${TAG}_pytest_$A1.log 2>&1; tail -3 gpurun_out/${TAG}_pytest_$A1.log ;;
+    inputs) timeout 900 python tools/time_inputs.py > gpurun_out/${TAG}_inputs.txt 2>&1; tail -30 gpurun_out/${TAG}_inputs.txt ;;
+    trace)  UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py > gpurun_out/${TAG}_wave_trace_$A1.txt 2>&1; tail -40 gpurun_out/${TAG}_wave_trace_$A1.txt ;;
+    *) echo "unknown stage $NAME" ;;
+  esac
+done
+echo done

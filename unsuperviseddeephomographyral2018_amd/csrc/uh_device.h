@@ -339,83 +339,6 @@ __device__ __forceinline__ double wave_sum(double v) {
 // wave index of this thread as a scalar (threadIdx.x >> 6 is wave-uniform but the compiler cannot know)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// ---- "the block that takes the last ticket finishes" -------------------------------------------------------------------
-// A reduction whose second stage used to be a one-block finish KERNEL (5-7 us of launch latency for < 1 us of work) ends
-// in its producer instead: every block publishes its partial sums, takes a ticket from a device counter, and the block
-// that draws the last one reads all partials back and writes the result.  gfx950 has 8 XCDs with one L2 each and no
-// coherence between them for ordinary accesses, so
-//   * partials are published with agent-scope atomic EXCHANGES (performed at the memory side, past the L2s; a returned
-//     value means the write is done) -- not plain stores + __threadfence(), whose release would write back the whole L2;
-//   * the finishing block reads them with sc1 loads (agent scope: they do not hit a stale line of its own L2);
-//   * the counter is an agent-scope atomic add; the last block resets it to 0, so a counter is 0 between launches.
-// The counters live in a library-owned pool (uh::ticket_slots, uh_misc.hip).
-__device__ __forceinline__ void publish_i32(int* p, int v) {
-    const int old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" :: "v"(old));                             // ask for the returned value: its arrival = the exchange is done
-}
-__device__ __forceinline__ void publish_f32(float* p, float v) { publish_i32((int*)p, __float_as_int(v)); }
-// Reader of published partials.  COHERENT = true: buffer loads with the sc1 bit (agent scope, what an agent-scope atomic
-// load compiles to) -- but as ORDINARY loads, so that the compiler keeps many of them in flight; a loop of atomic loads
-// issues one at a time and costs a full memory latency per element (measured: 8 us for a 675-float finish).  They cannot
-// move above take_last_ticket()'s barrier, which is all the ordering the pattern needs.
-template <bool COHERENT>
-struct PartialReader {
-    __amdgpu_buffer_rsrc_t r;
-    const void* base;
-    __device__ __forceinline__ PartialReader(const void* p, unsigned bytes) : r(make_rsrc(p, bytes)), base(p) {}
-    __device__ __forceinline__ float f32(unsigned i) const {
-        if constexpr (COHERENT) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, i * 4u, 0, /*sc1*/ 16));
-        else return ((const float*)base)[i];
-    }
-    // element i if `ok`, else 0 -- without a branch, so that a batch of them stays in flight together
-    __device__ __forceinline__ float f32_if(bool ok, unsigned i) const {
-        if constexpr (COHERENT)       // an offset past num_records reads as 0
-            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? i * 4u : 0xfffffff0u, 0, /*sc1*/ 16));
-        else { const float t = ((const float*)base)[ok ? i : 0u]; return ok ? t : 0.f; }
-    }
-    __device__ __forceinline__ int i32_if(bool ok, unsigned i) const {
-        if constexpr (COHERENT) return (int)__builtin_amdgcn_raw_buffer_load_b32(r, ok ? i * 4u : 0xfffffff0u, 0, /*sc1*/ 16);
-        else { const int t = ((const int*)base)[ok ? i : 0u]; return ok ? t : 0; }
-    }
-    __device__ __forceinline__ int i32(unsigned i) const {
-        if constexpr (COHERENT) return (int)__builtin_amdgcn_raw_buffer_load_b32(r, i * 4u, 0, /*sc1*/ 16);
-        else return ((const int*)base)[i];
-    }
-};
-// Whole block calls it after its publish_*() calls; true (in every thread) in the block that took ticket `target - 1`.
-__device__ __forceinline__ bool take_last_ticket(int* ticket, int target, int* lds_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's exchanges have returned = are performed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old == target - 1;
-        if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *lds_flag = last;
-    }
-    __syncthreads();
-    return *lds_flag != 0;
-}
-// Two-level variant for grids whose blocks would all hit ONE counter (same-address agent-scope atomics are served one
-// after the other, ~20 ns each: 1024 blocks finishing together spent ~20 us queueing on a single ticket).  Blocks count on
-// their group's counter tickets[1 + group]; the block that completes a group counts on tickets[0]; the block that
-// completes tickets[0] is the last of the grid.  Pure counting tree: what the last block then does is unchanged.
-__device__ __forceinline__ bool take_last_ticket2(int* tickets, int group, int group_size, int n_groups, int* lds_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int last = 0;
-        const int old = __hip_atomic_fetch_add(tickets + 1 + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == group_size - 1) {
-            __hip_atomic_store(tickets + 1 + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int og = __hip_atomic_fetch_add(tickets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = og == n_groups - 1;
-            if (last) __hip_atomic_store(tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *lds_flag = last;
-    }
-    __syncthreads();
-    return *lds_flag != 0;
-}
 // LDS hand-over between the lanes of ONE wave (its ds ops execute in order; this only stops the compiler reordering)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -49,15 +49,6 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end(k, s); }
 };
 
-// `n` device ints that are 0 now and 0 again after the kernel that uses them as last-block tickets (uh_device.h,
-// take_last_ticket) -- or nullptr = "launch the separate finish kernel", which is the DEFAULT: the ticket route is
-// opt-in (environment UH_TICKETS=1), see uh_misc.hip.  Library-owned pool per device, handed out round-robin: a range can only be handed out twice at
-// once if more than TICKET_POOL / n such launches are in flight on DIFFERENT streams.  nullptr when n is too large or
-// when the pool does not exist yet and `s` is being captured (hipMalloc is not capturable) -- the caller then launches
-// the separate finish kernel instead.
-constexpr int TICKET_POOL = 16384;
-int* ticket_slots(int n, hipStream_t s);
-
 // uh_gather_patch_losses_forward with a second destination for l1_loss (uh_tail.hip writes the caller's loss scalar
 // from the loss kernel itself instead of a 4-byte copy node)
 int gather_patch_losses(const float* warped, const int* patch_idx, const float* target, const float* h4p, const float* gt,

@@ -22,23 +22,21 @@ constexpr int NLS = 7;      // |d|, d^2, smooth-l1, x^2, y^2, x*y, ssim
 constexpr int LPT = 4;      // patch pixels per thread of patch_losses_kernel
 
 // out[0..4] = rec, ssim, l1, l1_smooth, ncc;  out[5] = h_loss = sqrt(mean((h4p - gt)^2)) when h4p != NULL.
-// One block of 256 threads.  COHERENT: the partials come from other blocks of the running kernel (last-block ticket).
+// One block of 256 threads.
 struct LossFinish { const float* h4p; const float* gt; int nh; float* out; double inv_n, inv_ns;
                     float* l1_out; };      // optional second destination of l1_loss (uh_tail: the caller's loss scalar)
-template <bool COHERENT>
 __device__ __forceinline__ void patch_losses_finish(const float* __restrict__ partial, int nblk, const LossFinish& f,
                                                     double (*red)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double a[NLS + 1];
 #pragma unroll
     for (int k = 0; k <= NLS; ++k) a[k] = 0.0;
-    const PartialReader<COHERENT> rp(partial, (unsigned)(nblk * NLS * 4));
     for (int i0 = threadIdx.x; i0 < nblk; i0 += 256 * 4) {          // 4 rows x 7 loads in flight, added in row order
         float v[4][NLS];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int k = 0; k < NLS; ++k) v[q][k] = rp.f32_if(i0 + 256 * q < nblk, (unsigned)((i0 + 256 * q) * NLS + k));
+            for (int k = 0; k < NLS; ++k) { const bool ok = i0 + 256 * q < nblk; const float t = partial[ok ? (i0 + 256 * q) * NLS + k : 0]; v[q][k] = ok ? t : 0.f; }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -73,7 +71,7 @@ __device__ __forceinline__ void patch_losses_finish(const float* __restrict__ pa
 }
 __global__ __launch_bounds__(256) void patch_losses_finish_kernel(const float* __restrict__ partial, int nblk, LossFinish f) {
     __shared__ double red[NLS + 1][4];
-    patch_losses_finish<false>(partial, nblk, f, red);
+    patch_losses_finish(partial, nblk, f, red);
 }
 
 // one thread per patch pixel (i, j): its point-wise terms, plus the SSIM of the 3x3 window whose top-left
@@ -86,7 +84,7 @@ struct GatherArgs { const int* idx; float* pred; int HW; };
 template <int GC>
 __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                            float* __restrict__ partial, int P, int blocks_per_image,
-                                                           int* ticket, LossFinish fin, GatherArgs ga) {
+                                                           GatherArgs ga) {
     __shared__ float red[NLS][16];
     extern __shared__ float xt[];                 // GC > 0: LPT*256 + 2P + 3 floats
     const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x - b * blocks_per_image;
@@ -171,17 +169,7 @@ __global__ __launch_bounds__(256) void patch_losses_kernel(const float* __restri
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += r[k];
-        if (ticket) publish_f32(partial + (size_t)blockIdx.x * NLS + threadIdx.x, t);
-        else partial[(size_t)blockIdx.x * NLS + threadIdx.x] = t;
-    }
-    // last-block ticket (uh_device.h): the block that completes the grid computes the 16 outputs itself -- same code and
-    // summation order as patch_losses_finish_kernel, without that kernel's launch
-    if (ticket) {
-        __shared__ int last_flag;
-        __shared__ double fred[NLS + 1][4];
-        // counting tree: the image's blocks, then the images (one counter for all 1024 blocks serialises them)
-        if (take_last_ticket2(ticket, b, blocks_per_image, (int)gridDim.x / blocks_per_image, &last_flag))
-            patch_losses_finish<true>(partial, (int)gridDim.x, fin, fred);
+        partial[(size_t)blockIdx.x * NLS + threadIdx.x] = t;
     }
 }
 
@@ -312,10 +300,9 @@ static int launch_losses(const float* X, const float* target, const float* h4p, 
                          int B, int P, hipStream_t s, int GC, GatherArgs ga, float* l1_out = nullptr) {
     const int bpi = (P * P + 256 * LPT - 1) / (256 * LPT);
     const LossFinish fin{h4p, gt, B * 8, out16, 1.0 / ((double)B * P * P), 1.0 / ((double)B * (P - 2) * (P - 2)), l1_out};
-    int* ticket = ticket_slots(1 + B, s);        // NULL (the default, see uh_host.h): separate finish kernel
     const unsigned shm = GC ? (unsigned)((LPT * 256 + 2 * P + 3) * sizeof(float)) : 0u;
 #define UH_LOSSES(GCV) launch_timed_shm(UH_K_LOSSES, patch_losses_kernel<GCV>, dim3((unsigned)B * bpi), dim3(256), shm, s, X, target, \
-                                        (float*)workspace, P, bpi, ticket, fin, ga)
+                                        (float*)workspace, P, bpi, ga)
     switch (GC) {
         case 0: UH_LOSSES(0); break;
         case 1: UH_LOSSES(1); break;
@@ -325,7 +312,7 @@ static int launch_losses(const float* X, const float* target, const float* h4p, 
     }
 #undef UH_LOSSES
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || ticket) return (int)e;
+    if (e != hipSuccess) return (int)e;
     launch_timed(UH_K_LOSSES_FIN, patch_losses_finish_kernel, dim3(1), dim3(256), s, (const float*)workspace, B * bpi, fin);
     return (int)hipGetLastError();
 }

@@ -9,7 +9,6 @@
 #include "uh_device.h"
 #include "uh_host.h"
 #include <mutex>
-#include <cstdlib>
 #include <vector>
 
 namespace uh {
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(256) void gray_patch_backward_fixup_kernel(const fl
             const int v = e / P, u = e - v * P;
             direct = (x0 + u < W) && (y0 + v < H) && t == (y0 + v) * W + (x0 + u);
         }
-        if (!direct) {
+        if (!direct && t >= 0 && t < HW) {                  // (an index outside the frame -- tf.gather would raise -- adds nothing)
             float* q = dWarped + ((size_t)k * HW + t) * C;
             const float g = dPred[i] / (float)C;
 #pragma unroll
@@ -88,45 +87,26 @@ __global__ __launch_bounds__(256) void gray_patch_backward_fixup_kernel(const fl
 constexpr int L1_BLOCKS = 1024;
 
 // the grid's partial sums -> loss, by one wave, f64, fixed order
-template <bool COHERENT>
-__device__ __forceinline__ void l1_finish(const float* __restrict__ partial, float* __restrict__ loss, int nblk, double inv_n,
-                                          int lane) {
-    double acc = 0.0;
-    const PartialReader<COHERENT> rp(partial, (unsigned)(nblk * 4));
-    for (int i = lane; i < nblk; i += 64) acc += (double)rp.f32((unsigned)i);
-    acc = wave_sum(acc);
-    if (lane == 0) loss[0] = (float)(acc * inv_n);
-}
-
-// ticket != NULL: the block that completes the grid also runs l1_finish (last-block ticket, uh_device.h)
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ pred,
                                                          const float* __restrict__ target,
-                                                         float* __restrict__ partial, size_t n, int* ticket,
-                                                         float* __restrict__ loss, double inv_n) {
+                                                         float* __restrict__ partial, size_t n) {
     __shared__ float red[4];
-    __shared__ int last_flag;
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         acc += fabsf(pred[i] - target[i]);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float t = (red[0] + red[1]) + (red[2] + red[3]);
-        if (ticket) publish_f32(partial + blockIdx.x, t); else partial[blockIdx.x] = t;
-    }
-    if (ticket) {
-        constexpr int GS = 32;                                            // counting tree: groups of 32 blocks (uh_device.h)
-        const int ng = ((int)gridDim.x + GS - 1) / GS, grp = (int)blockIdx.x / GS;
-        const int gsz = min(GS, (int)gridDim.x - grp * GS);
-        if (take_last_ticket2(ticket, grp, gsz, ng, &last_flag) && threadIdx.x < 64)
-            l1_finish<true>(partial, loss, (int)gridDim.x, inv_n, (int)threadIdx.x);
-    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(64) void l1_finish_kernel(const float* __restrict__ partial, float* __restrict__ loss,
                                                        int nblk, double inv_n) {
-    l1_finish<false>(partial, loss, nblk, inv_n, (int)threadIdx.x);
+    const int lane = (int)threadIdx.x;
+    double acc = 0.0;
+    for (int i = lane; i < nblk; i += 64) acc += (double)partial[i];
+    acc = wave_sum(acc);
+    if (lane == 0) loss[0] = (float)(acc * inv_n);
 }
 
 __global__ __launch_bounds__(256) void l1_backward_kernel(const float* __restrict__ pred,
@@ -178,42 +158,6 @@ void prof_end(int kernel, hipStream_t s) {
             return;
         }
     }
-}
-
-// ---- ticket pool (uh_host.h) ---------------------------------------------------------------------------------------------
-namespace {
-std::mutex g_tk_mu;
-constexpr int TK_MAX_DEV = 64;
-int* g_tk_pool[TK_MAX_DEV];
-int g_tk_cursor[TK_MAX_DEV];
-}  // namespace
-int* ticket_slots(int n, hipStream_t s) {
-    if (n <= 0 || n > TICKET_POOL / 4) return nullptr;
-    // Opt-in (UH_TICKETS=1).  Measured on MI355X (profiles/r02_ticket_ab_step_breakdown.txt): finishing in the last block
-    // costs what the finish kernel costs -- publish, ticket and read-back are three dependent ~2 us round trips to the
-    // memory side -- so the default stays the two-kernel route, which needs no shared counters.  Read per call: the tests
-    // switch it to cover both routes.
-    const char* e = getenv("UH_TICKETS");
-    if (!e || e[0] != '1') return nullptr;
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TK_MAX_DEV) { (void)hipGetLastError(); return nullptr; }
-    std::lock_guard<std::mutex> lk(g_tk_mu);
-    if (!g_tk_pool[dev]) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (st != hipStreamCaptureStatusNone) return nullptr;          // cannot allocate inside a capture
-        int* p = nullptr;
-        if (hipMalloc(&p, TICKET_POOL * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        // (synchronous, and waited for: the first user may run on a non-blocking stream that does not order with stream 0)
-        if (hipMemset(p, 0, TICKET_POOL * sizeof(int)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
-            (void)hipGetLastError(); (void)hipFree(p); return nullptr;
-        }
-        g_tk_pool[dev] = p;
-    }
-    if (g_tk_cursor[dev] + n > TICKET_POOL) g_tk_cursor[dev] = 0;
-    int* r = g_tk_pool[dev] + g_tk_cursor[dev];
-    g_tk_cursor[dev] += n;
-    return r;
 }
 
 }  // namespace uh
@@ -339,11 +283,8 @@ extern "C" int uh_l1_loss_forward(const float* pred, const float* target, float*
     size_t gb = (n + 255) / 256;
     const int nblk = (int)(gb > (size_t)L1_BLOCKS ? (size_t)L1_BLOCKS : gb);
     ProfScope prof(UH_K_L1_FWD, s);
-    int* ticket = ticket_slots(1 + (nblk + 31) / 32, s);
-    hipLaunchKernelGGL(l1_partial_kernel, dim3(nblk), dim3(256), 0, s, pred, target, (float*)workspace, n, ticket, loss,
-                       1.0 / (double)n);
-    if (!ticket)
-        hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, loss, nblk, 1.0 / (double)n);
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(nblk), dim3(256), 0, s, pred, target, (float*)workspace, n);
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, loss, nblk, 1.0 / (double)n);
     return (int)hipGetLastError();
 }
 

@@ -424,7 +424,6 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
 // (x0, y0).  The finish kernel treats every other tile's partial as the 0 the dense kernel would have written there
 // WITHOUT reading it (same summation order, same bits, no memset of the partial buffer).
 struct PatchArgs { const int* idx; int P, PP; int* confirmed; int nrx, nry;
-                   int* ticket; float* dTheta;        // ticket != NULL (both modes): the image's last block also finishes it
                    int kind; const float* pred; const float* target; const float* stats; const float* dLoss; size_t n; };
 __host__ __device__ inline void patch_tile_range(int x0, int y0, int P, int tiles_x, int tiles_y, int th, int& txlo, int& txhi,
                                                  int& tylo, int& tyhi) {
@@ -440,22 +439,36 @@ __host__ __device__ inline void patch_tile_range(int x0, int y0, int P, int tile
 // arithmetic, f64 accumulation, fixed order).  For the dataloader's rectangles nothing is added.
 // Where the patch gradient comes from: kind < 0 -> dPred [B,PP] as given; kind = UH_LOSS_* (point-wise kinds) -> formed on
 // the fly from (pred, target, lc) exactly as uh_patch_loss_backward would have written it (uh_warp_patch_loss_backward).
+// ge / C, correctly rounded (the dense chain's uh_gray_patch_backward divides), without the v_div_* sequence: exact
+// scalings for C = 1, 2, 4; for C = 3 Markstein's correction step -- y = RN(1/3), q = RN(a y) is within 1 ulp of a/3,
+// r = a - 3q is exact in one fma, RN(q + r y) is the correctly rounded quotient.  (Below |a| ~ 1e-30 the residual can leave
+// the f32 range and the quotient may be 1 ulp of a DENORMAL off the division's: a gradient of that size adds nothing.)
+template <int C>
+__device__ __forceinline__ float div_by_channels(float a) {
+    if constexpr (C == 3) {
+        const float y = 1.0f / 3.0f;
+        const float q = a * y;
+        const float r = __builtin_fmaf(-3.0f, q, a);
+        return __builtin_fmaf(r, y, q);
+    } else {
+        return a * (1.0f / (float)C);
+    }
+}
 struct LossSrc { int kind; const float* pred; const float* target; LossCoef lc; };
 __device__ __forceinline__ float patch_grad(const LossSrc& ls, const float* __restrict__ dPred, size_t e) {
     return ls.kind < 0 ? dPred[e] : loss_grad_point(ls.kind, ls.pred[e], ls.target[e], ls.lc);
 }
 struct PatchFinish { const float* U; const float* theta; const float* dPred; const int* idx; const int* confirmed;
                      int P, PP, H, W; float sx, sy; int tiles_x; LossSrc ls; };
-// `red` = 64 doubles of LDS private to the calling wave.  COHERENT: the partials were published by OTHER blocks of the
-// running kernel (last-block ticket, uh_device.h) and are read with agent-scope loads.
-template <int C, bool PATCH, bool COHERENT>
+// `red` = 64 doubles of LDS private to the calling wave.
+template <int C, bool PATCH>
 __device__ __forceinline__ void finish_image(const float* __restrict__ partial, float* __restrict__ dTheta, int tiles, int b,
                                              const PatchFinish& pf, double* red, int lane) {
     double a = 0.0;
     int txlo = 0, txhi = -1, tylo = 0, tyhi = -1;                        // PATCH: the tiles the bandwidth kernel wrote
     if constexpr (PATCH) {
-        if (pf.P > 0) {
-            const int o = pf.idx[(size_t)b * pf.PP];
+        const int o = pf.P > 0 ? pf.idx[(size_t)b * pf.PP] : -1;
+        if (o >= 0 && o < pf.H * pf.W) {                                  // (an out-of-range anchor: no rectangle, as in the kernel)
             patch_tile_range(o - (o / pf.W) * pf.W, o / pf.W, pf.P, pf.tiles_x, tiles / pf.tiles_x, TH_B, txlo, txhi, tylo, tyhi);
         }
     }
@@ -464,8 +477,9 @@ __device__ __forceinline__ void finish_image(const float* __restrict__ partial, 
         const int ty = tile / pf.tiles_x, tx = tile - ty * pf.tiles_x;
         return tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi;
     };
-    const PartialReader<COHERENT> rp(partial + (size_t)b * tiles * 9, (unsigned)(tiles * 9 * 4));
-    const PartialReader<COHERENT> rc(pf.confirmed + (size_t)b * tiles, (unsigned)(tiles * 4));
+    const float* __restrict__ rp = partial + (size_t)b * tiles * 9;
+    // element i if `ok`, else 0 -- without a branch, so that a batch of them stays in flight together
+    auto f32_if = [&](bool ok, int i) { const float t = rp[ok ? i : 0]; return ok ? t : 0.f; };
     if (lane < 63) {
         const int n = tiles * 9;
         // batches of FB loads in flight, added in index order (the sums do not depend on FB)
@@ -478,7 +492,7 @@ __device__ __forceinline__ void finish_image(const float* __restrict__ partial, 
 #pragma unroll
                 for (int q = 0; q < FB; ++q) {
                     const int e = e0 + 63 * q;
-                    v[q] = rp.f32_if(e < n && tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi, (unsigned)e);
+                    v[q] = f32_if(e < n && tx >= txlo && tx <= txhi && ty >= tylo && ty <= tyhi, e);
                     tx += 7;
                     while (tx >= pf.tiles_x) { tx -= pf.tiles_x; ++ty; }
                 }
@@ -489,7 +503,7 @@ __device__ __forceinline__ void finish_image(const float* __restrict__ partial, 
             for (int e0 = lane; e0 < n; e0 += 63 * FB) {
                 float v[FB];
 #pragma unroll
-                for (int q = 0; q < FB; ++q) v[q] = rp.f32_if(e0 + 63 * q < n, (unsigned)(e0 + 63 * q));
+                for (int q = 0; q < FB; ++q) v[q] = f32_if(e0 + 63 * q < n, e0 + 63 * q);
 #pragma unroll
                 for (int q = 0; q < FB; ++q) a += (double)v[q];
             }
@@ -500,13 +514,15 @@ __device__ __forceinline__ void finish_image(const float* __restrict__ partial, 
     if constexpr (PATCH) {
         {
             int cnt = 0;
-            for (int e = lane; e < tiles; e += 64) cnt += rc.i32_if(written(e), (unsigned)e);
+            const int* __restrict__ rc = pf.confirmed + (size_t)b * tiles;
+            for (int e = lane; e < tiles; e += 64) cnt += written(e) ? rc[e] : 0;
             cnt = (int)wave_sum((double)cnt);
             if (cnt != pf.PP) {
                 const int H = pf.H, W = pf.W, P = pf.P, PP = pf.PP;
                 const int* idx = pf.idx + (size_t)b * PP;
                 const int o = idx[0];
-                const int y0 = o / W, x0 = o - y0 * W;
+                const bool anchored = P > 0 && o >= 0 && o < H * W;
+                const int y0 = anchored ? o / W : 0, x0 = anchored ? o - y0 * W : 0;
                 const Theta th = load_theta(pf.theta, b);
                 const SrcGeom g = make_geom<C>(W, H);
                 const float* Ub = pf.U + (size_t)b * H * W * C;
@@ -517,11 +533,12 @@ __device__ __forceinline__ void finish_image(const float* __restrict__ partial, 
                 for (int e = lane; e < PP; e += 64) {
                     const int t = idx[e];
                     bool direct = false;
-                    if (P > 0) {
+                    if (anchored) {
                         const int v = e / P, u = e - v * P;
                         direct = (x0 + u < W) && (y0 + v < H) && t == (y0 + v) * W + (x0 + u);
                     }
                     if (direct) continue;
+                    if (t < 0 || t >= H * W) continue;                  // not a pixel of the frame (tf.gather would raise): adds nothing
                     const int row = t / W, col = t - row * W;
                     const float gx = lin_at(pf.sx, col), gy = lin_at(pf.sy, row);
                     const Coord c = make_coord(th, th.a[0] * gx, th.a[3] * gx, th.a[6] * gx, gy, g);
@@ -569,7 +586,7 @@ __global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if constexpr (PATCH) { if (pf.ls.kind >= 0) pf.ls.lc = loss_coef(pf.ls.kind, stats, dLoss ? dLoss[0] : 1.0f, n); }
-    if (b < B) finish_image<C, PATCH, false>(partial, dTheta, tiles, b, pf, red[wave], lane);
+    if (b < B) finish_image<C, PATCH>(partial, dTheta, tiles, b, pf, red[wave], lane);
 }
 
 template <int C, bool WANT_DU, bool SMALL, bool PATCH = false>
@@ -591,6 +608,7 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
         b = v / per;
         const int r = v - b * per, j = r / pa.nrx, i = r - j * pa.nrx;
         const int o = pa.idx[(size_t)b * pa.PP];                         // uniform -> scalar load
+        if (o < 0 || o >= H * W) return;                                 // no valid anchor: every entry is a stray (finish kernel)
         py0 = o / W; px0 = o - py0 * W;
         int txlo, txhi, tylo, tyhi;
         patch_tile_range(px0, py0, pa.P, tiles_x, tiles / tiles_x, TH_B, txlo, txhi, tylo, tyhi);
@@ -644,7 +662,7 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                     const size_t e = (size_t)b * pa.PP + (size_t)(v * pa.P + u);
                     const int ie = pa.idx[e];
                     const float ge = patch_grad(ls, dOut, e);            // (loaded alongside idx[e], not after the compare)
-                    if (ie == row * W + col) { gv = ge / (float)C; ++nconf; }
+                    if (ie == row * W + col) { gv = div_by_channels<C>(ge); ++nconf; }
                 }
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) G[k].v[ch] = gv;
@@ -809,29 +827,12 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < NWAVE * 4; ++k) t += rr[k];
-        if (pa.ticket) publish_f32(partial + (size_t)v * 9 + threadIdx.x, t);
-        else partial[(size_t)v * 9 + threadIdx.x] = t;
+        partial[(size_t)v * 9 + threadIdx.x] = t;
     }
     if constexpr (PATCH) {
         if (threadIdx.x == 0) {
             const int nc = (redc[0] + redc[1]) + (redc[2] + redc[3]);
-            if (pa.ticket) publish_i32(pa.confirmed + v, nc); else pa.confirmed[v] = nc;
-        }
-    }
-    // The block that completes image b reduces its tiles itself (finish_image, same code and order as the stand-alone
-    // finish kernel -> same bits) instead of leaving that to a second, launch-latency-bound kernel.
-    if (pa.ticket) {                                                     // uniform
-        __shared__ int last_flag;
-        __shared__ double fred[64];
-        int target = tiles;
-        if constexpr (PATCH) {
-            int txlo, txhi, tylo, tyhi;
-            patch_tile_range(px0, py0, pa.P, tiles_x, tiles / tiles_x, TH_B, txlo, txhi, tylo, tyhi);
-            target = (txhi - txlo + 1) * (tyhi - tylo + 1);
-        }
-        if (take_last_ticket(pa.ticket + b, target, &last_flag) && wave == 0) {
-            const PatchFinish pf{U, theta, dOut, pa.idx, pa.confirmed, pa.P, pa.PP, H, W, sx, sy, tiles_x, ls};
-            finish_image<C, PATCH, true>(partial, pa.dTheta, tiles, b, pf, fred, lane);
+            pa.confirmed[v] = nc;
         }
     }
 }
@@ -913,13 +914,13 @@ extern "C" size_t uh_warp_backward_workspace_bytes(int B, int H, int W, int C, i
 
 template <int C>
 static void launch_bwd(const float* U, const float* theta, const float* dOut, float* partial, float* dU, int B,
-                       int H, int W, int oh, int ow, hipStream_t s, int* ticket, float* dTheta) {
+                       int H, int W, int oh, int ow, hipStream_t s) {
     const TileGeom g = tile_geom(oh, ow, TH_B);
     const unsigned nblk = (unsigned)B * g.tiles;
     const bool sm = small_image(H, W, C);
 #define UH_BWD(DU, SM) launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, DU, SM, false>, dim3(nblk), dim3(256), s, U, \
                                    theta, dOut, partial, dU, H, W, oh, ow, lin_step(ow), lin_step(oh), g.tiles_x, g.tiles, nblk, \
-                                   PatchArgs{nullptr, 0, 0, nullptr, 0, 0, ticket, dTheta, -1, nullptr, nullptr, nullptr, nullptr, 0})
+                                   PatchArgs{nullptr, 0, 0, nullptr, 0, 0, -1, nullptr, nullptr, nullptr, nullptr, 0})
     if (dU) { if (sm) UH_BWD(true, true); else UH_BWD(true, false); }
     else    { if (sm) UH_BWD(false, true); else UH_BWD(false, false); }
 #undef UH_BWD
@@ -937,22 +938,19 @@ extern "C" int uh_warp_backward(const float* U, const float* theta, const float*
         if (e != hipSuccess) return (int)e;
     }
     float* partial = (float*)workspace;
-    int* ticket = ticket_slots(B, s);            // one counter per image; NULL (the default, see uh_host.h): two kernels
     {
         switch (C) {
-            case 1: launch_bwd<1>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
-            case 2: launch_bwd<2>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
-            case 3: launch_bwd<3>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
-            default: launch_bwd<4>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s, ticket, dTheta); break;
+            case 1: launch_bwd<1>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
+            case 2: launch_bwd<2>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
+            case 3: launch_bwd<3>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
+            default: launch_bwd<4>(U, theta, dOut, partial, dU, B, H, W, oh, ow, s); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
-    if (!ticket) {
-        const TileGeom g = tile_geom(oh, ow, TH_B);
-        launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel<1, false>, dim3((B + 3) / 4), dim3(256), s,
-                     (const float*)partial, dTheta, g.tiles, B, PatchFinish{}, (const float*)nullptr, (const float*)nullptr, (size_t)0);
-    }
+    const TileGeom g = tile_geom(oh, ow, TH_B);
+    launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel<1, false>, dim3((B + 3) / 4), dim3(256), s,
+                 (const float*)partial, dTheta, g.tiles, B, PatchFinish{}, (const float*)nullptr, (const float*)nullptr, (size_t)0);
     return (int)hipGetLastError();
 }
 
@@ -975,15 +973,13 @@ static void launch_patch_bwd(const float* U, const float* theta, const PatchGrad
     const unsigned nblk = (unsigned)B * nrx * nry;
     const size_t n = (size_t)B * PP;
     // P == 0 (no rectangle): no block tile is launched per image, the finish kernel does all the work
-    int* ticket = P > 0 ? ticket_slots(B, s) : nullptr;
-    const PatchArgs pa{idx, P, PP, confirmed, nrx, nry, ticket, dTheta, src.kind, src.pred, src.target, src.stats, src.dLoss, n};
+    const PatchArgs pa{idx, P, PP, confirmed, nrx, nry, src.kind, src.pred, src.target, src.stats, src.dLoss, n};
     if (small_image(H, W, C))
         launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, true, true>, dim3(nblk), dim3(256), s, U, theta, src.dPred,
                      partial, (float*)nullptr, H, W, H, W, lin_step(W), lin_step(H), g.tiles_x, g.tiles, nblk, pa);
     else
         launch_timed(UH_K_WARP_BWD, warp_backward_kernel<C, false, false, true>, dim3(nblk), dim3(256), s, U, theta, src.dPred,
                      partial, (float*)nullptr, H, W, H, W, lin_step(W), lin_step(H), g.tiles_x, g.tiles, nblk, pa);
-    if (ticket) return;
     const PatchFinish pf{U, theta, src.dPred, idx, confirmed, P, PP, H, W, lin_step(W), lin_step(H), g.tiles_x,
                          LossSrc{src.kind, src.pred, src.target, LossCoef{0.f, 0.f, 0.f}}};
     launch_timed(UH_K_WARP_BWD_FIN, warp_backward_finish_kernel<C, true>, dim3((B + 3) / 4), dim3(256), s,

@@ -7,8 +7,9 @@ torch tensors (NHWC logical layout, as the reference's dataloader emits) instead
 
 What runs where
   * VGG regressor (homography_model.py:107-133): stock PyTorch-ROCm (MIOpen / hipBLASLt), channels_last.
-  * solve_DLT, transform, l1 loss (:169-269, :328): the HIP C-ABI library via ops.py -- no torch math.
-  * the monitoring losses (:136-166, :286-352): a handful of torch elementwise ops on [B,P,P,1].
+  * solve_DLT, transform and all six losses of build_losses (:136-166, :169-269, :286-352), values and the gradient
+    of the one being trained on: the HIP C-ABI library via ops.py -- no torch math (the supervised h_loss that
+    carries a gradient, :288, is one torch expression on [B,8]).
 """
 from collections import namedtuple
 
@@ -233,30 +234,6 @@ class HomographyModel(object):
         train = lt if (torch.is_grad_enabled() and lt != 'h_loss') else None
         self.warped_images, self.pred_I2, self._mon = ops.warp_gather_losses(
             self.I, self._theta, self.patch_indices, P, self.I2_aug, self.pred_h4p, self.gt, train=train)
-
-    # ---- homography_model.py:136-166 ----------------------------------------------------------------
-    def _L1_smooth_loss(self, x, y):
-        abs_diff = torch.abs(x - y)
-        return torch.mean(torch.where(abs_diff < 1, 0.5 * abs_diff * abs_diff, abs_diff - 0.5))
-
-    def _SSIM_loss(self, x, y, size=3):
-        C1 = 0.01 ** 2
-        C2 = 0.03 ** 2
-        x = x.permute(0, 3, 1, 2); y = y.permute(0, 3, 1, 2)
-        pool = lambda v: F.avg_pool2d(v, size, 1)
-        mu_x = pool(x); mu_y = pool(y)
-        sigma_x = pool(x ** 2) - mu_x ** 2
-        sigma_y = pool(y ** 2) - mu_y ** 2
-        sigma_xy = pool(x * y) - mu_x * mu_y
-        SSIM_n = (2 * mu_x * mu_y + C1) * (2 * sigma_xy + C2)
-        SSIM_d = (mu_x ** 2 + mu_y ** 2 + C1) * (sigma_x + sigma_y + C2)
-        SSIM = SSIM_n / SSIM_d
-        return torch.clamp((1 - SSIM) / 2, 0, 1).permute(0, 2, 3, 1)
-
-    def _NCC_loss(self, x, y):
-        len_x = torch.sqrt(torch.sum(x * x))
-        len_y = torch.sqrt(torch.sum(y * y))
-        return torch.sqrt(torch.sum((x / len_x - y / len_y) ** 2))
 
     # ---- homography_model.py:271-352 ----------------------------------------------------------------
     def build_losses(self):

@@ -262,9 +262,8 @@ class _WarpGatherLosses(torch.autograd.Function):
     allows (homography_model.py:257-269, 286-352): forward = uh_warp_forward (the full `warped` frame, as the reference
     materialises it) + uh_gather_patch_losses_forward (gray + gather + all six loss values); backward =
     uh_warp_patch_loss_backward (the loss gradient is formed inside the sparse warp backward: no dPred tensor).  Same
-    values, bit for bit, as warp_gather -> patch_losses (tests/test_gpu_parity) in 3 + 2 kernels instead of 4 + 3 (2 + 1
-    with UH_TICKETS=1, which runs the two finish stages in their producers' last blocks).  SSIM's gradient is a
-    stencil: it keeps uh_patch_loss_backward."""
+    values, bit for bit, as warp_gather -> patch_losses (tests/test_gpu_parity) in 3 + 2 kernels instead of 4 + 3.  SSIM's gradient is a stencil: it keeps
+    uh_patch_loss_backward."""
 
     @staticmethod
     def forward(ctx, U, theta, patch_idx, patch_size, target, h4p, gt, kind):
