@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- image-pairs/s of the unsupervised-homography TRAIN STEP on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: re-executes itself under
+                                                                  torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -19,7 +20,11 @@ Rank 0 prints ONE JSON line; extra objects:
                   time): algorithmic bytes per launch / average launch duration measured with HIP
                   events on the launch stream (uh_profile_*) inside the timed region, vs 8 TB/s HBM.
   cpu_baseline -- the reference-equivalent op graph on torch-CPU (oracle/hotpath_torch.py) timed on this
-                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                  box's host cores on a bounded sample of the same workload: the GPU leg's batch and corner offsets,
+                  copied to the host (rank 0, N=1 only).
+  quality      -- the metric's second half, "mean corner error": a from-scratch unsupervised l1_loss training with the
+                  reference's hyper-parameters for a fixed step budget OUTSIDE the timed region, then the reference's
+                  test statistics (homography_CNN_synthetic.py:391-401,573-579) on held-out pairs (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -60,47 +65,99 @@ def parse():
                     help='1: add gt + N(0, 2 px) to the regressor output inside the timed steps, so that theta follows SURVEY '
                          '8(d)\'s mid-training law (perspective, clipped and far-field tiles) instead of the near-identity a '
                          '25-step-old regressor predicts; 0: the raw regressor')
+    ap.add_argument('--quality', type=int, default=1, help='0: skip the mean-corner-error training run')
+    ap.add_argument('--quality_steps', type=int, default=8000, help='training steps of the quality run (~5.6 ms each)')
+    ap.add_argument('--quality_pool', type=int, default=384, help='in-HBM pool of pre-generated training batches (118 MB each)')
+    ap.add_argument('--quality_texture', default='multiscale', choices=['smooth', 'multiscale'])
     ap.add_argument('--cpu_sample_pairs', type=int, default=64, help='CPU leg: batch size (default = the GPU batch)')
     ap.add_argument('--cpu_sample_steps', type=int, default=12, help='CPU leg: timed steps after one warm-up step')
     ap.add_argument('--cpu_threads', type=int, default=32, help='host threads for the CPU leg (capped at nproc)')
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """Reference-equivalent op graph on torch-CPU: full train step (same VGG, TF-graph-shaped hot path with
-    autograd backward, Adam) on a bounded sample: `cpu_sample_pairs` pairs x `cpu_sample_steps` steps."""
+def cpu_baseline(args, batch, h4p_offset):
+    """Reference-equivalent op graph on torch-CPU: full train step (same VGG, TF-graph-shaped hot path with autograd
+    backward, Adam) on the GPU leg's OWN workload: its batch (seed 100) and its per-pair corner offsets (the mid-training
+    theta law) are copied to the host, the first `cpu_sample_pairs` pairs are stepped `cpu_sample_steps` times."""
     from oracle import hotpath_torch as OT
     from unsuperviseddeephomographyral2018_amd.homography_model import VGGRegressor
     cores = min(os.cpu_count() or 1, args.cpu_threads)     # small ops: more threads only add contention
     torch.set_num_threads(cores)
-    B, H, W, P = args.cpu_sample_pairs, args.img_h, args.img_w, args.patch_size
-    g = torch.Generator().manual_seed(0)
-    x0 = torch.randint(args.rho, W - args.rho - P + 1, (B,), generator=g)
-    y0 = torch.randint(args.rho, H - args.rho - P + 1, (B,), generator=g)
-    u = torch.arange(P)
-    batch = {
-        'I_aug': torch.randn(B, H, W, 3, generator=g),
-        'I1_aug': torch.randn(B, P, P, 1, generator=g), 'I2_aug': torch.randn(B, P, P, 1, generator=g),
-        'pts1': torch.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).float(),
-        'gt': torch.randint(-args.rho, args.rho + 1, (B, 8), generator=g).float(),
-        'patch_indices': ((u[None, :, None] + y0[:, None, None]) * W + (u[None, None, :] + x0[:, None, None])
-                          ).reshape(B, P * P).int(),
-    }
+    B, H, W, P = min(args.cpu_sample_pairs, batch['I_aug'].shape[0]), args.img_h, args.img_w, args.patch_size
+    cb = {k: v[:B].detach().cpu().contiguous() for k, v in batch.items() if torch.is_tensor(v)}
+    off = h4p_offset[:B].detach().cpu() if h4p_offset is not None else None
+    torch.manual_seed(1234)
     net = VGGRegressor(P).train()
-    # start from a predictor near the ground truth so the homographies are realistic (same law as the GPU run)
-    with torch.no_grad():
-        net.fc2.weight.zero_()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-    OT.train_step_cpu(net, opt, batch, W, H, P, args.loss_type)               # warm-up (allocator, threads)
+    OT.train_step_cpu(net, opt, cb, W, H, P, args.loss_type, h4p_offset=off)   # warm-up (allocator, threads)
     t0 = time.perf_counter()
     for _ in range(args.cpu_sample_steps):
-        OT.train_step_cpu(net, opt, batch, W, H, P, args.loss_type)
+        OT.train_step_cpu(net, opt, cb, W, H, P, args.loss_type, h4p_offset=off)
     dt = time.perf_counter() - t0
     return {'value': round(B * args.cpu_sample_steps / dt, 2), 'unit': 'image-pairs/s', 'cores': cores,
             'kind': 'port',
-            'sample': '%d train steps of %d pairs (%dx%d, P=%d), torch-CPU op-graph restatement of the TF graph '
-                      '+ same VGG + Adam, %d threads of %d host cores, %.1f s' % (args.cpu_sample_steps, B, H, W, P, cores,
-                                                                                 os.cpu_count() or 1, dt)}
+            'sample': '%d train steps of the GPU leg\'s own batch (synthetic.make_batch seed 100, first %d pairs, %dx%d, P=%d) '
+                      'under the same theta law (%s), copied to the host: torch-CPU op-graph restatement of the TF graph + '
+                      'same VGG + Adam, %d threads of %d host cores, %.1f s' % (
+                          args.cpu_sample_steps, B, H, W, P,
+                          'regressor + gt + N(0,2px), generator seed 4321' if off is not None else 'raw regressor',
+                          cores, os.cpu_count() or 1, dt)}
+
+
+def quality_run(device, args):
+    """Mean corner error (BASELINE.json's metric, second half): unsupervised photometric l1_loss from scratch with the
+    reference's hyper-parameters (Adam, lr 1e-4, staircase decay with decay_steps_for(), batch 64, 240x320, P=128,
+    RHO=45; homography_CNN_synthetic.py:161-183) for a FIXED budget of steps, then the reference's test loop
+    (TestHomography, :391-401,573-579: 3 passes over `num_test_data` held-out pairs, bounded RMSE, failure rate).
+    Training pairs cycle through an in-HBM pool drawn with the law of gen_synthetic_data.py:42-64; the test pairs come
+    from disjoint seeds.  Runs outside the timed region, on its own freshly initialised variables."""
+    import contextlib
+    from unsuperviseddeephomographyral2018_amd import synthetic
+    from unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic import TestHomography, TrainStep, build_parser
+    B = args.per_gpu_batch
+    targs = build_parser().parse_args([
+        '--mode', 'train', '--loss_type', 'l1_loss', '--batch_size', str(B), '--img_h', str(args.img_h),
+        '--img_w', str(args.img_w), '--patch_size', str(args.patch_size), '--rho', str(args.rho), '--lr', '1e-4',
+        '--min_lr', '.9e-4', '--texture', args.quality_texture, '--num_test_data', '1024', '--seed', '0'])
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    step_fn = TrainStep(targs, device, 1)
+    pool = [synthetic.make_batch(B, args.img_h, args.img_w, args.patch_size, args.rho, seed=1000 + i, device=device,
+                                 kind=args.quality_texture) for i in range(max(1, args.quality_pool))]
+    gen = torch.Generator().manual_seed(7919)
+    order, first, last = [], [], []
+    for s in range(args.quality_steps):
+        if not order:
+            order = torch.randperm(len(pool), generator=gen).tolist()
+        m = step_fn(pool[order.pop()])
+        if s < 100:
+            first.append(m.h_loss.detach())
+        if s >= args.quality_steps - 100:
+            last.append(m.h_loss.detach())
+    torch.cuda.synchronize(device)
+    t_train = time.perf_counter() - t0
+    with contextlib.redirect_stdout(sys.stderr):           # the test loop prints the reference's result lines
+        res = TestHomography(targs, step_fn=step_fn).run()
+    # what an un-trained predictor scores on the same held-out law: pred_h4p = 0 -> RMSE of gt itself
+    ident = []
+    for step in range(8):
+        b = synthetic.make_batch(B, args.img_h, args.img_w, args.patch_size, args.rho, seed=10_000_000 + step, device=device,
+                                 kind=args.quality_texture)
+        ident.append(torch.sqrt(torch.mean(b['gt'] ** 2, dim=1)).mean())
+    del pool
+    torch.cuda.empty_cache()
+    return {'mean_corner_error_px': round(res['mean_corner_error'], 3), 'fail_percent': round(res['fail_percent'], 3),
+            'identity_corner_error_px': round(float(torch.stack(ident).mean()), 3),
+            'train_steps': args.quality_steps, 'train_seconds': round(t_train, 1), 'test_pairs': res['num_pairs'],
+            'train_corner_error_px_first_100_steps': round(float(torch.stack(first).mean()), 3) if first else None,
+            'train_corner_error_px_last_100_steps': round(float(torch.stack(last).mean()), 3) if last else None,
+            'percentiles_px': {str(k): round(v, 3) for k, v in res['percentiles'].items()},
+            'hyper_parameters': 'reference defaults: Adam lr 1e-4, exponential_decay 0.96 every %d steps (staircase), batch %d, '
+                                'dropout 0.5, loss_type l1_loss (photometric)' % (int(step_fn.decay_steps), B),
+            'data': 'synthetic %s texture, pool of %d batches cycled in random order; test: %d held-out pairs x 3 passes '
+                    '(reference: MS-COCO crops, 150 000 steps)' % (args.quality_texture, args.quality_pool, 1024),
+            'note': 'fixed step budget (%d of the reference\'s 150 000 steps): not a converged model; longer runs under profiles/'
+                    % args.quality_steps}
 
 
 def tile_paths(theta, H, W, lds_bytes=6144, tile=16):
@@ -211,16 +268,30 @@ def config4_point(device, args):
     return r
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py
+    <same arguments>` -- one rank per GPU; the ranks pick RCCL when every rank has a device of its own and gloo otherwise
+    (dist.init_from_env), so the same command is a functional run on a 1-GPU box."""
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)                                   # does not return
     from unsuperviseddeephomographyral2018_amd import _lib, dist as uh_dist, synthetic
     from unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic import TrainStep, build_parser
     _lib.load()                                             # fail loudly if the HIP library is missing
     rank, world, local = uh_dist.init_from_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
-        args.gpus = world
+    args.gpus = world                                       # the launcher's world size is authoritative
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
     device = torch.device('cuda', local)
@@ -306,7 +377,6 @@ def main():
                          'frac': round(2 * B * args.img_h * args.img_w * 3 * 4 / (us2 * 1e-6) / HBM_PEAK, 4),
                          'tile_paths': tile_paths(th2, args.img_h, args.img_w)}
     loss_val = float(model.loss.detach())
-    h_loss_val = float(model.h_loss.detach())              # mean corner error (RMSE px) of the last batch: the net is 35 steps old
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     exchange = None
@@ -367,7 +437,7 @@ def main():
         except Exception:
             pass
     out = {
-        'metric': 'image-pairs/sec (train step), 128x128 patch RHO=45', 'value': round(value, 1),
+        'metric': 'image-pairs/sec (train step) + mean corner error, 128x128 patch RHO=45', 'value': round(value, 1),
         'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -378,8 +448,8 @@ def main():
                        ' (fused patch kernel)' if args.fused_patch else ''),
                    'global_batch': global_batch, 'loss_type': args.loss_type, 'parallelism': 'dp%d' % world,
                    'final_loss': round(loss_val, 6),
-                   ('corner_error_px_of_offset_prediction' if args.mid_training_theta else
-                    'mean_corner_error_px_after_%d_steps' % (args.steps + args.warmup)): round(h_loss_val, 3)},
+                   'visible_devices': torch.cuda.device_count(),
+                   'device': torch.cuda.get_device_name(device)},
         'roofline': roofline,
     }
     out['config']['in_step_theta'] = in_step_theta
@@ -388,13 +458,21 @@ def main():
     if world > 1:
         out['config']['rccl_world_size'] = torch.distributed.get_world_size()
         out['config']['dist_backend'] = torch.distributed.get_backend()
+        try:
+            out['config']['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            out['config']['rccl_version'] = None
         out['exchange'] = exchange
     if world == 1 and args.north_star:
         out['north_star_point'] = north_star_point(device, args)
     if world == 1 and args.config4:
         out['config4_point'] = config4_point(device, args)
     if world == 1 and args.cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args)
+        out['cpu_baseline'] = cpu_baseline(args, batch, step_fn.h4p_offset)
+    if world == 1 and args.quality and args.loss_type == 'l1_loss':
+        del step_fn, model
+        torch.cuda.empty_cache()
+        out['quality'] = quality_run(device, args)
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

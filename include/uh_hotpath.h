@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define UH_ABI_VERSION 3
+#define UH_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define UH_API __attribute__((visibility("default")))
@@ -90,6 +90,11 @@ UH_API int uh_dlt_backward(const float* pts1, const float* h4p, const float* H,
                     const float* dH, const float* dtheta,
                     const float* M_host, const float* Minv_host,
                     float* dh4p, int B, unsigned flags, uh_stream_t stream);
+
+/* How many pairs UH_DLT_ZERO_NONFINITE_GRAD has zeroed on the current device since the last reset (the one deliberate
+ * departure from the reference, which lets tf.matrix_solve's NaN through, homography_model.py:242: the trainer prints
+ * this so that the guard is never silent).  Synchronous: waits for the device; reset != 0 clears the counter.        */
+UH_API int uh_dlt_zeroed_pairs(unsigned long long* count, int reset);
 
 /* ---- Spatial transformer ----------------------------------------------------------------------
  * U [B,H,W,C], theta [B,9] -> out [B,oh,ow,C].  `condition` (device float[1], may be NULL) receives

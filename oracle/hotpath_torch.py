@@ -178,11 +178,14 @@ def photometric_loss(loss_type, I, I2, pts1, pred_h4p, patch_indices, img_w, img
     return patch_loss(loss_type, pred_I2, I2), pred_I2
 
 
-def train_step_cpu(net, opt, batch, img_w, img_h, patch_size, loss_type='l1_loss'):
+def train_step_cpu(net, opt, batch, img_w, img_h, patch_size, loss_type='l1_loss', h4p_offset=None):
     """One full reference-equivalent train step on CPU tensors (VGG from the product package is plain
-    torch and runs on CPU; the hot path is the op graph above)."""
+    torch and runs on CPU; the hot path is the op graph above).  h4p_offset: bench.py's hook -- per-pair corner
+    offsets added to the regressor's output, the same tensor the GPU leg adds (TrainStep.h4p_offset)."""
     opt.zero_grad(set_to_none=True)
     pred_h4p = net(torch.cat([batch['I1_aug'], batch['I2_aug']], 3))
+    if h4p_offset is not None:
+        pred_h4p = pred_h4p + h4p_offset
     if loss_type == 'h_loss':
         loss = torch.sqrt(torch.mean((pred_h4p - batch['gt']) ** 2))
         with torch.no_grad():

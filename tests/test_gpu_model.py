@@ -318,15 +318,21 @@ def test_degenerate_pair_does_not_poison_the_variables(pkg, dev, kind):
         bad[1] = torch.tensor([100., 100.] * 4, device=dev) - batch['pts1'][1]      # all four p2 corners on one point
     else:
         bad[1] = 1e30                                                               # products overflow -> inf - inf
-    grads = {}
+    from unsuperviseddeephomographyral2018_amd import _lib
+    grads, zeroed = {}, {}
     for name, h4p0, guard in (('good', good, True), ('bad_guarded', bad, True), ('bad_raw', bad, False)):
         h = h4p0.clone().requires_grad_(True)
+        _lib.dlt_zeroed_pairs(reset=True)
         _, theta = ops.solve_dlt(batch['pts1'], h, W, H, zero_nonfinite_grad=guard)
         _, pred = ops.warp_gather(batch['I_aug'], theta, batch['patch_indices'], P)
         loss = ops.patch_losses(pred, batch['I2_aug'], train='l1_loss')[2]
         loss.backward()
         grads[name] = h.grad.clone()
+        zeroed[name] = _lib.dlt_zeroed_pairs(reset=True)
     assert torch.isfinite(grads['bad_guarded']).all()
+    # the guard is never silent: the library counts the pairs it zeroed (the trainer prints the count)
+    assert zeroed['good'] == 0 and zeroed['bad_raw'] == 0
+    assert zeroed['bad_guarded'] == (0 if torch.isfinite(grads['bad_raw'][1]).all() else 1)
     keep = [0, 2, 3]
     assert torch.equal(grads['bad_guarded'][keep], grads['good'][keep])             # the other pairs are untouched
     if not torch.isfinite(grads['bad_raw'][1]).all():                               # the guard fired for pair 1
@@ -422,3 +428,49 @@ def test_whole_step_hipgraph_trains(pkg, dev):
     other = synthetic.make_batch(B, H, W, P, RHO, seed=22, device=dev)
     m = step(other)
     assert torch.equal(step._static['I_aug'], other['I_aug']) and torch.equal(m.I, step._static['I_aug'])
+
+
+def test_step_graph_resume_keeps_the_adam_state(pkg, dev):
+    """A --step_graph run resumed from a checkpoint: the capture's eager warm-up must put back the RESTORED Adam moments and
+    step counts (not zeros), so the first replayed steps match the eager steps of a run resumed from the same checkpoint.
+    Dropout is what differs between the two routes' RNG consumption, so the comparison runs with it off (eval-mode net);
+    with the state zeroed instead of restored, bias correction restarts and the first update is ~lr-sized in every
+    coordinate: the two runs would differ by orders of magnitude more than the tolerance here."""
+    hm, synthetic, drv = pkg
+    common = ['--batch_size', str(B), '--img_h', str(H), '--img_w', str(W), '--patch_size', str(P), '--rho', str(RHO),
+              '--loss_type', 'l1_loss', '--lr', '1e-4']
+    batch = synthetic.make_batch(B, H, W, P, RHO, seed=31, device=dev)
+    torch.manual_seed(0)
+    first = drv.TrainStep(drv.build_parser().parse_args(common), dev, 1)
+    for _ in range(12):
+        first(batch)
+    sd = copy.deepcopy(first.state_dict())
+    w_ckpt = first.net.fc2.weight.detach().clone()
+
+    def resumed(graph):
+        a = drv.build_parser().parse_args(common + ['--step_graph', 'True' if graph else 'False'])
+        torch.manual_seed(5)
+        st = drv.TrainStep(a, dev, 1)
+        st.load_state_dict(copy.deepcopy(sd))
+        import torch.nn.functional as F
+        orig = F.dropout
+        F.dropout = lambda x, p=0.5, training=True, inplace=False: x       # dropout off on both routes
+        try:
+            for _ in range(3):
+                st(batch)
+        finally:
+            F.dropout = orig
+        torch.cuda.synchronize()
+        return st
+    eager, graph = resumed(False), resumed(True)
+    assert graph._graph is not None and graph.global_step == eager.global_step == 15
+    # Adam's step counter continued from the checkpoint on both routes
+    se = [float(s['step']) for s in eager.opt.state.values()]
+    sg = [float(s['step']) for s in graph.opt.state.values()]
+    assert se == sg and se[0] == 15.0
+    moved = float((eager.net.fc2.weight - w_ckpt).abs().max())
+    diff = float((eager.net.fc2.weight - graph.net.fc2.weight).abs().max())
+    assert moved > 0 and diff <= 0.05 * moved, (moved, diff)
+    for (n, pe), pg in zip(eager.net.named_parameters(), graph.net.parameters()):
+        d = float((pe - pg).abs().max()); m = float((pe - dict(first.net.named_parameters())[n]).abs().max())
+        assert d <= 0.1 * max(m, 1e-12), (n, d, m)

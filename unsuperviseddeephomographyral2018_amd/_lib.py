@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UH_LIB_PATH lets a developer A/B a differently-built copy of the SAME library (tools/); it is not a fallback.
 LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hotpath.so')
 
-UH_ABI_VERSION = 3
+UH_ABI_VERSION = 4
 UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
 UH_DLT_ZERO_NONFINITE_GRAD = 8
@@ -27,6 +27,7 @@ SIGNATURES = {
     'uh_error_string': (C.c_char_p, [_i]),
     'uh_dlt_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _u, _p]),
     'uh_dlt_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _u, _p]),
+    'uh_dlt_zeroed_pairs': (_i, [_p, _i]),
     'uh_warp_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'uh_warp_forward_literal': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'uh_warp_backward_workspace_bytes': (_z, [_i, _i, _i, _i, _i, _i]),
@@ -99,6 +100,13 @@ KERNEL_IDS = {'dlt_forward': 0, 'dlt_backward': 1, 'warp_forward': 2, 'warp_back
               'warp_patch_l1_fused': 9, 'warp_patch_l1_finish': 10, 'patch_losses': 11, 'patch_losses_finish': 12,
               'prepare_inputs': 13, 'bias_relu_forward': 14, 'bias_relu_backward': 15,
               'patch_loss_backward': 16}
+
+
+def dlt_zeroed_pairs(reset=False):
+    """Pairs whose d loss / d pred_h4p UH_DLT_ZERO_NONFINITE_GRAD zeroed on the current device since the last reset."""
+    n = C.c_ulonglong(0)
+    check(load().uh_dlt_zeroed_pairs(C.byref(n), 1 if reset else 0), 'uh_dlt_zeroed_pairs')
+    return int(n.value)
 
 
 def profile_enable(on, only=None):

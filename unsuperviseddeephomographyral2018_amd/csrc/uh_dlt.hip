@@ -119,6 +119,9 @@ __global__ __launch_bounds__(256) void dlt_forward_kernel(const float* __restric
     }
 }
 
+// pairs whose gradient UH_DLT_ZERO_NONFINITE_GRAD zeroed since the last reset, on this device (uh_dlt_zeroed_pairs)
+__device__ unsigned long long g_dlt_zeroed_pairs = 0ull;
+
 // Backward: g_b = A^-T g_h (tf MatrixSolveGrad: matrix_solve(A, grad, adjoint=True), i.e. an LU of
 // A^T), g_A = -g_b h^T; only columns 6,7 of A and the rhs depend on p2 = pts1 + h4p, so
 //   d/dx'_i =  g_b[2i+1] * (h6 x_i + h7 y_i + 1),   d/dy'_i = -g_b[2i] * (h6 x_i + h7 y_i + 1).
@@ -162,7 +165,10 @@ __global__ __launch_bounds__(256) void dlt_backward_kernel(const float* __restri
         float v = (float)((lane & 1) ? -gb_even * s : gb_odd * s);
         if (zero_nonfinite) {                               // UH_DLT_ZERO_NONFINITE_GRAD: all 8 or nothing
             const bool bad = !(fabsf(v) <= 3.402823466e38f);          // NaN or Inf
-            if (__ballot(bad) != 0ull) v = 0.f;                       // (only lanes 0..7 are active here)
+            if (__ballot(bad) != 0ull) {                              // (only lanes 0..7 are active here)
+                v = 0.f;
+                if (lane == 0) atomicAdd(&g_dlt_zeroed_pairs, 1ull);  // rare: once in millions of pairs
+            }
         }
         dh4p[(size_t)sys * 8 + lane] = v;
     }
@@ -214,4 +220,16 @@ extern "C" int uh_dlt_backward(const float* pts1, const float* h4p, const float*
     else
         hipLaunchKernelGGL(dlt_backward_kernel<float>, grid, block, 0, s, pts1, h4p, H, dH, dtheta, MT, MinvT, dh4p, B, zn);
     return (int)hipGetLastError();
+}
+
+extern "C" int uh_dlt_zeroed_pairs(unsigned long long* count, int reset) {
+    // synchronous (waits for the device): call it at log time, never inside a stream capture
+    if (!count) return UH_E_NULL;
+    hipError_t e = hipMemcpyFromSymbol(count, HIP_SYMBOL(uh::g_dlt_zeroed_pairs), sizeof(*count));
+    if (e != hipSuccess) return (int)e;
+    if (reset) {
+        const unsigned long long z = 0ull;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(uh::g_dlt_zeroed_pairs), &z, sizeof(z));
+    }
+    return (int)e;
 }

@@ -37,7 +37,10 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = os.environ.get('UH_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            # RCCL needs one device per rank; more ranks than visible GPUs (functional runs of the N > 1 path on a
+            # 1-GPU box) fall back to gloo by themselves, as does a CPU-only process
+            enough = torch.cuda.is_available() and torch.cuda.device_count() >= int(os.environ.get('LOCAL_WORLD_SIZE', world))
+            backend = os.environ.get('UH_DIST_BACKEND') or ('nccl' if enough else 'gloo')
         if torch.cuda.is_available():                                      # "nccl" IS RCCL on ROCm
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -75,6 +75,10 @@ def build_parser():
     p.add_argument('--fused_patch', type=str2bool, default='False',
                    help='l1_loss only: fused patch kernel instead of the full-frame warp')
     p.add_argument('--solve_f64', type=str2bool, default='False', help='carry the 8x8 DLT solve in f64')
+    p.add_argument('--zero_nonfinite_grad', type=str2bool, default='True',
+                   help='train mode: a pair whose d loss / d pred_h4p is NaN / Inf (degenerate predicted corners) contributes '
+                        'no gradient instead of poisoning every variable (UH_DLT_ZERO_NONFINITE_GRAD).  False = the '
+                        'reference\'s behaviour: tf.matrix_solve + autodiff pass the NaN on.  The log line counts the pairs.')
     p.add_argument('--step_graph', type=str2bool, default='False',
                    help='capture the whole training step (convs, hot path, Adam) into one hipGraph and replay it')
     p.add_argument('--graph_tail', type=str2bool, default='False',
@@ -164,8 +168,11 @@ class TrainStep(object):
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         # The eager warm-up below (MIOpen find, allocator, Adam state creation) must not count as training: snapshot the
         # variables, the optimizer state and the RNG streams (dropout) and put them back, so that step k of a
-        # --step_graph run sees exactly what step k of an eager run sees.
+        # --step_graph run sees exactly what step k of an eager run sees -- also when the state was just restored from a
+        # checkpoint (--resume): the Adam moments and step counts are copied back, not zeroed.
         net_sd = copy.deepcopy(self.net.state_dict())
+        opt_before = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                      for p, st in self.opt.state.items()}
         rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -175,15 +182,22 @@ class TrainStep(object):
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.net.load_state_dict(net_sd)
-        with torch.no_grad():                            # Adam: keep the (capturable) state tensors, zero their contents
-            for st in self.opt.state.values():
-                for v in st.values():
+        with torch.no_grad():        # Adam: keep the (capturable) state TENSORS the graph will update, restore their contents
+            for p, st in self.opt.state.items():
+                old = opt_before.get(p)
+                for k, v in st.items():
                     if torch.is_tensor(v):
-                        v.zero_()
+                        if old is not None and torch.is_tensor(old.get(k)):
+                            v.copy_(old[k])
+                        else:
+                            v.zero_()                    # the state did not exist before the warm-up: a fresh optimizer
         torch.set_rng_state(rng_cpu); torch.cuda.set_rng_state(rng_dev, self.device)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._graph_model = self._forward_backward_update(self._static)
+
+    def _zero_nonfinite(self):
+        return bool(getattr(self.args, 'zero_nonfinite_grad', True)) and self.args.mode == 'train'
 
     def _zero_or_reset(self):
         if self.averager is not None:
@@ -195,7 +209,7 @@ class TrainStep(object):
         self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
-                                h4p_offset=self.h4p_offset)
+                                h4p_offset=self.h4p_offset, zero_nonfinite_grad=self._zero_nonfinite())
         model.loss.backward()
         if self.averager is not None:
             self.averager.finish()
@@ -232,7 +246,8 @@ class TrainStep(object):
         self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
-                                graph_tail=getattr(self.args, 'graph_tail', False), h4p_offset=self.h4p_offset)
+                                graph_tail=getattr(self.args, 'graph_tail', False), h4p_offset=self.h4p_offset,
+                                zero_nonfinite_grad=self._zero_nonfinite())
         model.loss.backward()
         if self.averager is not None:
             self.averager.finish()
@@ -294,6 +309,9 @@ def train(args):
     window = torch.zeros(len(names), device=device)
     win_n = 0
     nonfinite_steps = torch.zeros((), device=device)
+    from . import _lib
+    _lib.dlt_zeroed_pairs(reset=True)
+    zeroed_pairs = 0
     t0 = time.time()
     for step in range(start_step, start_step + args.num_total_steps):
         if disk is not None:
@@ -320,10 +338,13 @@ def train(args):
             avg = (totals / n).tolist()                      # running means since the start, as the reference prints (:345-352)
             win = (window / win_n).tolist()                  # ... and the mean over the steps since the previous log line
             dt = time.time() - t0
+            zeroed_pairs += _lib.dlt_zeroed_pairs(reset=True)       # (synchronous read of a device counter: log time only)
             print('Train: step %d  ' % step + ', '.join('%s %.6f' % (k, v) for k, v in zip(names, avg))
                   + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
                   + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)])
-                  + ('  | %d steps with a non-finite loss value so far' % int(nonfinite_steps) if float(nonfinite_steps) else ''),
+                  + ('  | %d steps with a non-finite loss value so far' % int(nonfinite_steps) if float(nonfinite_steps) else '')
+                  + ('  | %d pairs had a non-finite gradient zeroed so far (--zero_nonfinite_grad; the reference would have '
+                     'propagated NaN)' % zeroed_pairs if zeroed_pairs else ''),
                   flush=True)
             window.zero_(); win_n = 0
         if rank == 0 and step and step % args.save_every == 0:
