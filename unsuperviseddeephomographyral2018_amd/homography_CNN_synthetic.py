@@ -261,6 +261,15 @@ class TrainStep(object):
     def load_state_dict(self, sd, retrain=False):
         self.net.load_state_dict(sd['net'])
         self.opt.load_state_dict(sd['opt'])
+        # Optimizer.load_state_dict also restores the SAVED run's param-group options; whether Adam is capturable and holds
+        # its lr in a device tensor is a property of THIS run (--step_graph), not of the checkpoint
+        for g in self.opt.param_groups:
+            g['capturable'] = self.step_graph
+            lr = float(g['lr'])
+            g['lr'] = torch.tensor(lr, device=self.device) if self.step_graph else lr
+        for st in self.opt.state.values():                  # fused / capturable Adam keeps `step` as a device f32 tensor
+            if torch.is_tensor(st.get('step')) and self.device.type == 'cuda':
+                st['step'] = st['step'].to(device=self.device, dtype=torch.float32)
         self.global_step = 0 if retrain else sd['global_step']        # (:314-317)
 
 
