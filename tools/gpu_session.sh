@@ -17,7 +17,7 @@
 #   trace:V         per-wave phase trace with the -DUH_WARP_TRACE variant V (tools/trace_waves.py)
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 TAG=$1; shift
-COMMIT=$(cat gpurun_out/.commit 2>/dev/null || echo unknown)
+COMMIT=${UH_COMMIT:-unknown}
 VDIR=unsuperviseddeephomographyral2018_amd/lib/variants
 MCFG=${MCFG:-"128,240,320,128,45;128,480,640,128,64"}
 BENCH="python /root/repo/bench.py --steps 30 --warmup 5 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0"
@@ -54,7 +54,10 @@ for ST in "$@"; do
             done
             python tools/show_micro.py gpurun_out/${TAG}_micro.jsonl 2>/dev/null | tail -40 ;;
     vtests) UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_model.py -m gpu -q --tb=short -x ${A2:+-k "$A2"} > gpurun_out/${TAG}_pytest_$A1.log 2>&1; tail -3 gpurun_out/${TAG}_pytest_$A1.log ;;
-    inputs) timeout 900 python tools/time_inputs.py > gpurun_out/${TAG}_inputs.txt 2>&1; tail -30 gpurun_out/${TAG}_inputs.txt ;;
+    inputs) timeout 900 python tools/time_inputs.py > gpurun_out/${TAG}_inputs.txt 2>&1; tail -30 gpurun_out/${TAG}_inputs.txt
+            ( cd /tmp && rm -rf /tmp/profi_$TAG && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/profi_$TAG -o inp --output-format csv -- python /root/repo/tools/time_inputs.py --kernel_only 1 > /dev/null 2>&1 )
+            cp $(find /tmp/profi_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_inputs_kernel_stats.csv 2>/dev/null
+            grep prepare_inputs gpurun_out/${TAG}_inputs_kernel_stats.csv | cut -c1-220 ;;
     trace)  UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py > gpurun_out/${TAG}_wave_trace_$A1.txt 2>&1; tail -40 gpurun_out/${TAG}_wave_trace_$A1.txt ;;
     *) echo "unknown stage $NAME" ;;
   esac

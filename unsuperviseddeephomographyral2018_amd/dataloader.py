@@ -154,21 +154,68 @@ class Dataloader(object):
                        if self.gt is not None else torch.zeros(len(ids), 8, device=self.device))
         return batch
 
-    def stream(self):
+    def stream(self, prefetch=0):
         """Endless stream of full batches, the reference's tf.train.(shuffle_)batch queue (dataloader.py:255-262): the
         index list is cycled epoch after epoch (re-shuffled each time), so NO pair is ever dropped and a batch may
-        straddle two epochs.  Raises instead of spinning when there is nothing to deliver."""
+        straddle two epochs.  Raises instead of spinning when there is nothing to deliver.
+        prefetch > 0: a producer thread keeps up to `prefetch` finished batches queued (the reference's queue runners,
+        :230-235), so that image decoding on the host overlaps the training step on the GPU; same batches, same order."""
         B = self.params.batch_size
         if len(self.names) == 0:
             raise ValueError('Dataloader: %s lists no pairs' % self.params.filenames_file)
         if B <= 0:
             raise ValueError('Dataloader: batch_size must be positive')
+        if prefetch > 0:
+            return self._prefetched(self._sync_stream(), int(prefetch))
+        return self._sync_stream()
+
+    def _sync_stream(self):
+        B = self.params.batch_size
         pending = []
         while True:
             while len(pending) < B:
                 pending.extend(self._order())
             ids, pending = pending[:B], pending[B:]
             yield self._batch(ids)
+
+    def _prefetched(self, gen, depth):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=depth)
+        stop = threading.Event()
+
+        def producer():
+            try:
+                if self.device.type == 'cuda':
+                    torch.cuda.set_device(self.device)
+                for batch in gen:
+                    ev = None
+                    if self.device.type == 'cuda':           # the consumer's stream waits for the producer's kernels
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(self.device))
+                    while not stop.is_set():
+                        try:
+                            q.put((batch, ev), timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+            except BaseException as e:                        # delivered to the consumer, not swallowed
+                q.put((e, None))
+
+        t = threading.Thread(target=producer, daemon=True)
+        t.start()
+        try:
+            while True:
+                item, ev = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                yield item
+        finally:
+            stop.set()
 
     def __iter__(self):
         """One epoch = ceil(n / batch_size) full batches; the last one is completed with the first pairs of the next

@@ -308,7 +308,7 @@ def train(args):
                                         augment_list=args.augment_list, do_augment=args.do_augment)
         loader = uh_data.Dataloader(prm, shuffle=True, device=device, seed=args.seed * 1000 + rank)
 
-        disk = loader.stream()                 # endless, never drops a pair, raises on an empty list
+        disk = loader.stream(prefetch=4)       # endless, never drops a pair, raises on an empty list; decode overlaps the step
     pool, order = [], []
     if disk is None and args.data_pool > 0:
         pool = [synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
