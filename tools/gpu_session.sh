@@ -58,7 +58,9 @@ for ST in "$@"; do
             ( cd /tmp && rm -rf /tmp/profi_$TAG && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/profi_$TAG -o inp --output-format csv -- python /root/repo/tools/time_inputs.py --kernel_only 1 > /dev/null 2>&1 )
             cp $(find /tmp/profi_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_inputs_kernel_stats.csv 2>/dev/null
             grep prepare_inputs gpurun_out/${TAG}_inputs_kernel_stats.csv | cut -c1-220 ;;
-    trace)  UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py > gpurun_out/${TAG}_wave_trace_$A1.txt 2>&1; tail -40 gpurun_out/${TAG}_wave_trace_$A1.txt ;;
+    trace)  UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py > gpurun_out/${TAG}_wave_trace_$A1.jsonl 2>gpurun_out/${TAG}_wave_trace.err
+            UH_TRACE_BWD=1 UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py >> gpurun_out/${TAG}_wave_trace_$A1.jsonl 2>>gpurun_out/${TAG}_wave_trace.err
+            cut -c1-1500 gpurun_out/${TAG}_wave_trace_$A1.jsonl ;;
     *) echo "unknown stage $NAME" ;;
   esac
 done

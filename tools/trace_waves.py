@@ -18,17 +18,24 @@ nw = B * ((W + 63) // 64) * ((H + 15) // 16) * 4
 tr = torch.zeros(nw * 8, dtype=torch.int64, device=dev)
 out = torch.empty_like(U)
 p = lambda t: C.c_void_p(t.data_ptr())
+BWD = bool(os.environ.get('UH_TRACE_BWD'))        # trace the backward (dense dOut) instead of the forward
+if BWD:
+    dOut = torch.randn_like(U); dT = torch.empty(B, 9, device=dev)
+    nb = lib.uh_warp_backward_workspace_bytes(B, H, W, 3, H, W); ws = torch.empty(nb // 4, device=dev)
+    run = lambda: lib.uh_warp_backward(p(U), p(theta), p(dOut), p(dT), None, p(ws), nb, B, H, W, 3, H, W, None)
+else:
+    run = lambda: lib.uh_warp_forward(p(U), p(theta), p(out), None, B, H, W, 3, H, W, None)
 for _ in range(3):
-    lib.uh_warp_forward(p(U), p(theta), p(out), None, B, H, W, 3, H, W, None)
+    run()
 torch.cuda.synchronize()
 assert C.CDLL(_lib.LIB_PATH).uh_debug_set_trace(p(tr)) == 0
-lib.uh_warp_forward(p(U), p(theta), p(out), None, B, H, W, 3, H, W, None)
+run()
 torch.cuda.synchronize()
 t = tr.cpu().numpy().reshape(nw, 8).astype(np.int64)
 t = t[(t[:, 0] > 0) & (t[:, 7] > 0)]
 span = t[:, 7].max() - t[:, 0].min()
 life = t[:, 7] - t[:, 0]
-res = {'lib': os.path.basename(_lib.LIB_PATH), 'identity': bool(os.environ.get('UH_IDENTITY_THETA')), 'waves': int(len(t)), 'kernel_span_cycles': int(span), 'mean_wave_life': float(life.mean()),
+res = {'kernel': 'backward' if BWD else 'forward', 'lib': os.path.basename(_lib.LIB_PATH), 'identity': bool(os.environ.get('UH_IDENTITY_THETA')), 'waves': int(len(t)), 'kernel_span_cycles': int(span), 'mean_wave_life': float(life.mean()),
        'avg_resident_waves': float(life.sum() / span)}
 names = {0: 'A', 1: 'B', 2: 'C1', 3: 'C2'}
 for k, n in names.items():
@@ -37,7 +44,7 @@ for k, n in names.items():
         continue
     q = t[m]
     ph = {'coords+decide': (q[:, 1] - q[:, 0]).mean(), 'issue': (q[:, 2] - q[:, 1]).mean(), 'wait_data': (q[:, 3] - q[:, 2]).mean(),
-          'consume+store_issue': (q[:, 4] - q[:, 3]).mean(), 'store_drain': (q[:, 7] - q[:, 4]).mean()}
+          'consume+store_issue' if not BWD else 'accumulate': (q[:, 4] - q[:, 3]).mean(), 'store_drain' if not BWD else 'block_reduction': (q[:, 7] - q[:, 4]).mean()}
     res[n] = {'share_of_waves': round(float(m.mean()), 4), 'share_of_wave_time': round(float(life[m].sum() / life.sum()), 4),
               'mean_life': round(float(life[m].mean()), 1), 'p99_life': float(np.percentile(life[m], 99)),
               'phases': {a: round(float(b), 1) for a, b in ph.items()}, 'mean_dma_instr': round(float(q[:, 6].mean()), 2)}

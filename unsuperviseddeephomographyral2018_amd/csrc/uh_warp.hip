@@ -221,7 +221,9 @@ __device__ __forceinline__ void global_quad(__amdgpu_buffer_rsrc_t rin, unsigned
 }
 
 #ifdef UH_WARP_TRACE
-// Developer instrumentation (tools/trace_waves.py; never in the shipped library): lane 0 of every forward wave records
+// Developer instrumentation (tools/trace_waves.py; never in the shipped library): lane 0 of every wave (forward, and
+// the backward with UH_TRACE_BWD=1; s_memtime orders with memory waits, not with VALU work, so the compute phases are
+// approximate) records
 // s_memtime at its phase boundaries and the path it took.  trace[w*8 + ..] = t0 entry, t1 decision made, t2 loads /
 // DMA issued, t3 data landed, t4 stores issued, [5] path (0 A, 1 B, 2 C1, 3 C2), [6] DMA instructions.
 __device__ unsigned long long* g_trace = nullptr;
@@ -265,11 +267,14 @@ __global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
 
     Proj p[STEPS];
     float fx[STEPS], fy[STEPS];
+    {
+        float gyk[STEPS];
 #pragma unroll
-    for (int k = 0; k < STEPS; ++k) {
-        p[k] = project(th, A0, A3, A6, -1.0f + sy * (rowf0 + (float)(k * WY)), g);
-        fx[k] = floorf(p[k].x); fy[k] = floorf(p[k].y);                                         // (:101,103)
+        for (int k = 0; k < STEPS; ++k) gyk[k] = -1.0f + sy * (rowf0 + (float)(k * WY));
+        project_all<STEPS>(th, A0, A3, A6, gyk, g, p);          // one eps-guard test per wave instead of one per pixel
     }
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) { fx[k] = floorf(p[k].x); fy[k] = floorf(p[k].y); }         // (:101,103)
     const Extent e = wave_extent<STEPS>(fx, fy, g);
     UH_TR(1);
 
@@ -622,6 +627,10 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
     }
     const int col = (tx * NWAVE + wave) * TW + (lane & (TW - 1));
     const int row0 = ty * TH_B + (lane / TW);                              // this lane's first row
+#ifdef UH_WARP_TRACE
+    unsigned long long* trp = (g_trace && lane == 0) ? g_trace + ((size_t)v * NWAVE + wave) * 8 : nullptr;
+#endif
+    UH_TR(0);
     float acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = 0.f;
@@ -670,10 +679,12 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                 G[k] = buf_load<C, UH_WARP_GLOAD_AUX>(rg, voff, 0);
             }
             voff += (unsigned)WY * orow;
-            p[k] = project(th, A0, A3, A6, gy[k], g);
-            fx[k] = floorf(p[k].x); fy[k] = floorf(p[k].y);
         }
+        project_all<STEPS_B>(th, A0, A3, A6, gy, g, p);
+#pragma unroll
+        for (int k = 0; k < STEPS_B; ++k) { fx[k] = floorf(p[k].x); fy[k] = floorf(p[k].y); }
         const Extent e = wave_extent<STEPS_B>(fx, fy, g);
+        UH_TR(1);
         // one pixel's contribution to the nine sums
         // hx = x1f - x0f, hy = y1f - y0f (1 for an interior sample, 0 where the clip collapsed the pair).  With
         // ay0 = hy - ay1:  ay1 (Ic-Ia) + ay0 (Id-Ib) = ay1 [(Ic-Ia) - (Id-Ib)] + hy (Id-Ib)  -- the form used here: a
@@ -736,14 +747,18 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                     oa[k] = (unsigned)__builtin_fmaf(fyk, st.pitch, __builtin_fmaf(fxk, g.pixB, st.nbase));
                 }
                 const unsigned pitchi = (unsigned)(st.cpr * 16);
+                UH_TR(2); UH_TRV(5, 0); UH_TRV(6, st.nld);
                 stage_wait();
+                UH_TR(3);
 #pragma unroll
                 for (int k = 0; k < STEPS_B; ++k) {
                     Pix<C> Ia, Ib, Ic, Id;
                     lds_quad<C>(lds, oa[k], oa[k] + pitchi, Ia, Ib, Ic, Id);
                     accumulate(k, 1.0f - ax0[k], 1.0f - ay0[k], 1.0f, 1.0f, Ia, Ib, Ic, Id);
                 }
+                UH_TR(4);
             } else {                                                    // ---- path B
+                UH_TR(2); UH_TRV(5, 1); UH_TRV(6, 0);
 #pragma unroll
                 for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
                     Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];             // 4*BT_B gathers in flight
@@ -780,6 +795,7 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
                 return c;
             };
             // ---- path C2: clipped gather
+            UH_TR(2); UH_TRV(5, 3); UH_TRV(6, 0);
 #pragma unroll
             for (int k0 = 0; k0 < STEPS_B; k0 += BT_B) {
                 Pix<C> Ia[BT_B], Ib[BT_B], Ic[BT_B], Id[BT_B];             // 4*BT_B gathers in flight
@@ -809,6 +825,9 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
             }
         }
         acc[0] = gx * acc[2]; acc[3] = gx * acc[5]; acc[6] = gx * acc[8];
+#ifdef UH_WARP_TRACE
+        if (trp && trp[3] == 0) { UH_TR(3); UH_TR(4); }                   // (the gather paths stamp nothing between issue and here)
+#endif
     }
     // block reduction: DPP inside rows of 16 lanes, the 16 row sums of the block meet in LDS (fixed order)
 #pragma unroll
@@ -835,6 +854,7 @@ __global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
             pa.confirmed[v] = nc;
         }
     }
+    UH_TR(7);
 }
 
 // ------------------------------------------------------------------------------------------------
