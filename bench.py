@@ -160,7 +160,7 @@ def quality_run(device, args):
                     % args.quality_steps}
 
 
-def tile_paths(theta, H, W, lds_bytes=6144, tile=16):
+def tile_paths(theta, H, W, lds_bytes=5120, tile=16):
     """Which path each 16x16 wave tile of uh_warp_forward takes under `theta` [B,9] (csrc/uh_warp.hip): A = interior,
     tap rectangle fits the wave's LDS slice (LDS-DMA staged); B = interior, rectangle too large (gather); C1 / C2 = some
     tap clipped, rectangle of the clipped taps fits / does not fit.  Re-derived here with torch ops in f32 (statistics

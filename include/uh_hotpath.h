@@ -209,7 +209,8 @@ UH_API int uh_warp_patch_l1_fwdbwd(const float* U, const float* theta, const flo
  * transform + the l1 branch of build_losses and their backward             homography_model.py:169-269,321-330
  * A plan fixes the shapes and owns the graph cache (one captured hipGraph per distinct set of pointers + stream,
  * LRU of 8; the key also holds the CONTENTS of M / Minv, and after 8 consecutive misses the chain is enqueued eagerly instead of
- * re-captured); intermediates (theta, dtheta, warped, dPred, reduction partials) live in the caller's workspace.
+ * re-captured -- until one of the last 64 eagerly-run argument sets comes back, which is then captured on that second sighting);
+ * intermediates (theta, dtheta, warped, reduction partials) live in the caller's workspace.
  * uh_tail_run is serialised per plan; do not enqueue other work on `stream` from another thread during the call
  * (the first call with a new argument set stream-captures).  With UH_TAIL_GRAPH unset, or while the launch profiler
  * is on, or on the NULL stream, the kernels are enqueued directly.

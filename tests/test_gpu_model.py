@@ -249,7 +249,8 @@ def test_tail_plan_reentry_constants_and_address_churn(pkg, dev):
         corrupt the first one's loss / pred / H / gradient -- outputs are copies, not views of plan buffers;
     (2) the captured graph bakes M / Minv in as kernel arguments: re-running a plan with different M_host contents must
         re-capture, not replay stale constants;
-    (3) a caller that hands in freshly allocated tensors every step must not pay a capture per step."""
+    (3) a caller that hands in freshly allocated tensors every step must not pay a capture per step;
+    (4) ... and an argument set that repeats after that is captured again."""
     hm, synthetic, _ = pkg
     from unsuperviseddeephomographyral2018_amd import ops
     batch = synthetic.make_batch(B, H, W, P, RHO, seed=21, device=dev)
@@ -301,6 +302,17 @@ def test_tail_plan_reentry_constants_and_address_churn(pkg, dev):
             assert torch.equal(pi, ref[0][1])
         side.synchronize()
         assert plan.stats()['captures'] - c0 <= 9, plan.stats()
+        # (4) ... but the detector does not switch the graph route off for good: an argument set that COMES BACK (a pool
+        # of batches cycled by the trainer) is captured on its second sighting and replayed from then on
+        c1 = plan.stats()['captures']
+        for rep in range(4):
+            for Ui in held[:3]:
+                x = h1.clone().requires_grad_(True)
+                li, pi, _, _ = ops.photometric_tail(batch['pts1'], x, Ui, batch['I2_aug'], batch['patch_indices'], P, graph=True)
+                li.backward()
+                assert torch.equal(pi, ref[0][1]) and torch.equal(x.grad, ref[0][3])
+        side.synchronize()
+        assert 1 <= plan.stats()['captures'] - c1 <= 3, plan.stats()
 
 
 @pytest.mark.parametrize('kind', ['collapsed', 'overflow'])

@@ -396,6 +396,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   smooth : (|d| < 1 ? d : sign(d)) / N                                                        (:136-139)
 //   ncc    : -(1/ncc) [ (y/|y| - x/|x|)/|x| - x (<x,y>/|y| - |x|)/|x|^3 ]                        (:161-166)
 // A zero norm (rec == 0, ncc == 0, |x| == 0) is 0/0 in the reference's autodiff; 0 is written here.
+// rec and ncc divide by GLOBAL sums over the whole shard: one pair whose pred is NaN (degenerate predicted corners) makes
+// those sums NaN and with them every pair's dTheta -- so under UH_DLT_ZERO_NONFINITE_GRAD the DLT backward zeroes ALL B
+// rows for that step (the step is a no-op apart from Adam's moment decay), where l1 / l1_smooth / ssim lose only the bad
+// pair.  The reference would have propagated NaN into every variable in all five cases.  The trainer's log line counts the
+// zeroed pairs (uh_dlt_zeroed_pairs), so such a step shows up as B pairs at once.
 struct LossCoef { float c0, c1, c2; };
 __device__ __forceinline__ LossCoef loss_coef(int kind, const float* __restrict__ stats, float g, size_t n) {
     LossCoef c{0.f, 0.f, 0.f};

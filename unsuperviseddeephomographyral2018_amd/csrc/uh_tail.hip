@@ -26,6 +26,10 @@ struct uh_tail_plan {
     unsigned long long clock = 0;
     long long launches = 0, captures = 0;
     int misses_in_a_row = 0;          // capture thrash detector (see uh_tail_run)
+    // argument sets that were enqueued eagerly while the detector was tripped: a set seen a SECOND time is worth a capture
+    struct Seen { const void* key[12]; float mk[18]; };
+    std::vector<Seen> seen;
+    size_t seen_cursor = 0;
     std::mutex mu;
 };
 
@@ -128,11 +132,22 @@ extern "C" int uh_tail_run(uh_tail_plan* p, const float* pts1, const float* h4p,
         }
     }
     // A caller that hands in freshly allocated batches every step (new addresses each time) would pay a capture +
-    // instantiate on the hot path per step -- slower than the ten eager launches it replaces.  After a full cache
-    // worth of consecutive misses stop capturing and enqueue eagerly until an address set repeats.
+    // instantiate on the hot path per step -- slower than the seven eager launches it replaces.  After a full cache
+    // worth of consecutive misses stop capturing and enqueue eagerly -- but remember the last 64 argument sets, and
+    // capture again as soon as one of them comes back (a pool of batches that is cycled, a double-buffered loader):
+    // the detector must not turn --graph_tail off for good.
     if (++p->misses_in_a_row > 8) {
-        p->launches++;
-        return enqueue_chain(p, pts1, h4p, U, I2, patch_idx, M_host, Minv_host, H, pred, loss, dh4p, ws, s);
+        bool again = false;
+        for (auto& sn : p->seen)
+            if (std::memcmp(sn.key, key, sizeof(key)) == 0 && std::memcmp(sn.mk, mk, sizeof(mk)) == 0) { again = true; break; }
+        if (!again) {
+            uh_tail_plan::Seen sn;
+            std::memcpy(sn.key, key, sizeof(key)); std::memcpy(sn.mk, mk, sizeof(mk));
+            if (p->seen.size() < 64) p->seen.push_back(sn);
+            else { p->seen[p->seen_cursor] = sn; p->seen_cursor = (p->seen_cursor + 1) % 64; }
+            p->launches++;
+            return enqueue_chain(p, pts1, h4p, U, I2, patch_idx, M_host, Minv_host, H, pred, loss, dh4p, ws, s);
+        }
     }
     // capture the chain on the caller's stream (thread-local mode: other threads' HIP calls are unaffected)
     hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);

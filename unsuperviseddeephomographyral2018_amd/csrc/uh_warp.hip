@@ -40,7 +40,12 @@ namespace uh {
 #define UH_WARP_STEPS 4
 #endif
 #ifndef UH_WARP_LDS_PER_WAVE
-#define UH_WARP_LDS_PER_WAVE 6144  // forward: LDS slice per wave (path A holds rectangles up to this size)
+#define UH_WARP_LDS_PER_WAVE 5120  // forward: LDS slice per wave (path A holds rectangles up to this size).  5 KiB, not 6: with
+                                   // 80 VGPRs the register file admits 6 waves per SIMD, and 6 x 4 x 6 KiB = 144 KiB made LDS a second
+                                   // limit of exactly 6 blocks per CU -- a block whose last (gather) wave is still running then holds
+                                   // the LDS a new block needs although its other three waves' registers are free.  20 KiB blocks leave
+                                   // room for 8: -1.7 % at config 4, -3 % at 240x320 (profiles/r03_microbench_variants.jsonl, `l5`),
+                                   // although 3 % more tiles gather
 #endif
 #ifndef UH_WARP_LDS_PER_WAVE_BWD
 #define UH_WARP_LDS_PER_WAVE_BWD 6144
@@ -77,7 +82,7 @@ constexpr int BT_F = UH_WARP_FWD_BATCH;
 static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the steps");
 #ifndef UH_WARP_FWD_MINW
 #define UH_WARP_FWD_MINW 6        // __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow
-                                  // (6 x 4 waves x 6 KiB LDS slices = 144 KiB of the CU's 160 KiB; 80 VGPRs, no spill)
+                                  // (80 VGPRs, no spill; 6 blocks x 4 waves x 5 KiB LDS slices = 120 KiB of the CU's 160 KiB)
 #endif
 #ifndef UH_WARP_BWD_MINW
 #define UH_WARP_BWD_MINW 5        // 96 VGPRs without path C1 (no spill)
