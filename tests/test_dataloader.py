@@ -160,3 +160,41 @@ def test_dataloader_never_drops_pairs_and_never_spins(tmp_path, uh_lib_path):
             next(empty.stream())
     except ValueError:
         pass                                                                                          # raising at construction is fine too
+
+
+@pytest.mark.gpu
+def test_worker_processes_and_prefetch_deliver_the_same_batches(tmp_path, uh_lib_path):
+    """Dataloader(num_workers=3) (decode in worker processes into a shared frame ring, several batches in flight) and
+    stream(prefetch=2) (producer thread) deliver exactly the batches of the plain thread-pool loader, in the same order,
+    across an epoch boundary; a missing file surfaces as an exception in the consumer, not as a hang."""
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    rs = np.random.RandomState(11)
+    N, H, W, P = 10, 48, 64, 16
+    I = _frames(rs, N, H, W); Ip = _frames(rs, N, H, W)
+    x0 = rs.randint(4, W - P - 4, N); y0 = rs.randint(4, H - P - 4, N)
+    pts1 = np.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).astype(np.float32)
+    gt = np.arange(N * 8).reshape(N, 8).astype(np.float32)
+    ff, fp, fg = dl.write_dataset(str(tmp_path) + '/', I, Ip, pts1, gt)
+    prm = dl.dataloader_params(data_path=str(tmp_path) + '/', filenames_file=ff, pts1_file=fp, gt_file=fg, mode='train',
+                               batch_size=4, img_h=H, img_w=W, patch_size=P, augment_list=['normalize'], do_augment=0.5)
+    def take(n, **kw):
+        pf = kw.pop('prefetch', 0)
+        it = dl.Dataloader(prm, shuffle=True, seed=5, **kw).stream(prefetch=pf)
+        out = [next(it) for _ in range(n)]
+        it.close()
+        return out
+    ref = take(7)
+    for kw in (dict(num_workers=3), dict(prefetch=2), dict(num_workers=2, prefetch=3)):
+        got = take(7, **kw)
+        for a, b in zip(ref, got):
+            for k in ('I_aug', 'I_prime_aug', 'I1', 'I2_aug', 'patch_indices', 'gt', 'pts1'):
+                assert torch.equal(a[k], b[k]), (kw, k)
+    os.remove(os.path.join(str(tmp_path), 'I_prime', '3.png'))
+    for kw in (dict(num_workers=2), dict(num_workers=2, prefetch=2), dict(prefetch=2)):
+        it = dl.Dataloader(prm, shuffle=False, seed=5, num_workers=kw.get('num_workers', 0)).stream(prefetch=kw.get('prefetch', 0))
+        with pytest.raises(Exception):
+            for _ in range(4):
+                next(it)
+        it.close()

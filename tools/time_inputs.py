@@ -52,6 +52,7 @@ def main():
     ap.add_argument('--B', type=int, default=64)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--disk_pairs', type=int, default=1024)
+    ap.add_argument('--jpg_only', type=int, default=1, help='0: also time a PNG copy of the set (30 s to write)')
     ap.add_argument('--kernel_only', type=int, default=0, help='1: only part 1 (the run rocprofv3 --kernel-trace --stats wraps)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -124,7 +125,7 @@ def main():
     # on-disk set in the reference's layout, written from synthetic frames (uint8 round trip as gen_synthetic_data.py does)
     tmp = tempfile.mkdtemp(prefix='uh_disk_')
     try:
-        for fmt in ('jpg', 'png'):
+        for fmt in ('jpg',) if a.jpg_only else ('jpg', 'png'):
             root = os.path.join(tmp, fmt)
             n_pairs = a.disk_pairs
             frames, framesp, pts, gts = [], [], [], []
@@ -141,8 +142,8 @@ def main():
                                       img_h=H, img_w=W, patch_size=P, augment_list=['normalize'], do_augment=0.5)
             res = {'pairs_on_disk': n_pairs, 'write_seconds': round(t_write, 1),
                    'bytes_per_image': int(os.path.getsize(os.path.join(root, 'I', '0.' + fmt)))}
-            for pf in (0, 4):
-                loader = D.Dataloader(prm, shuffle=True, device=dev, seed=1)
+            for pf, nw in ((0, 0), (4, 0), (4, 16), (4, 48)):
+                loader = D.Dataloader(prm, shuffle=True, device=dev, seed=1, num_workers=nw)
                 st = loader.stream(prefetch=pf)
                 for _ in range(3):
                     next(st)
@@ -153,9 +154,10 @@ def main():
                     next(st)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / n
-                res['loader_alone_prefetch%d' % pf] = {'ms_per_batch': round(dt * 1e3, 2), 'pairs_per_s': round(B / dt)}
-                st2 = D.Dataloader(prm, shuffle=True, device=dev, seed=2).stream(prefetch=pf)
-                res['train_data_path_prefetch%d' % pf] = train_rate(lambda: next(st2), min(a.steps, 100), warm=5)
+                res['loader_alone_prefetch%d_workers%d' % (pf, nw)] = {'ms_per_batch': round(dt * 1e3, 2), 'pairs_per_s': round(B / dt)}
+                st2 = D.Dataloader(prm, shuffle=True, device=dev, seed=2, num_workers=nw).stream(prefetch=pf)
+                res['train_data_path_prefetch%d_workers%d' % (pf, nw)] = train_rate(lambda: next(st2), min(a.steps, 100), warm=5)
+                st.close(); st2.close()
                 del st, st2
             out['disk_' + fmt] = res
             print(json.dumps({'disk_' + fmt: res}, indent=1), flush=True)

@@ -8,6 +8,10 @@ parses the text files, decodes images (PIL, a thread pool -- JPEG entropy decodi
 augmentation parameters.  Same namedtuple, same text formats (np.savetxt rows, "a.jpg b.jpg" lines:
 utils/gen_synthetic_data.py:121-126), same output contract: the 9 tensors HomographyModel takes, NHWC f32.
 
+`Dataloader(num_workers=K)` decodes in K worker PROCESSES (`_decode_worker.py`: numpy + PIL only) into a shared uint8
+frame ring under /dev/shm instead of the thread pool -- Python threads serialise on the interpreter lock at ~2 000
+pairs/s, which is a fifth of what the train step consumes (profiles/r03_inputs_timing.txt).
+
 Differences, stated: shuffling is a seeded permutation per epoch instead of TF's min_after_dequeue window;
 `per_image_normalize` is not implemented (the reference's own branch references undefined names, :180-187);
 frames whose decoded size differs from (img_h, img_w) are area-resized with PIL's BOX filter (TF's AREA resize).
@@ -114,10 +118,11 @@ class Dataloader(object):
         <data_path>/I/<name>, <data_path>/I_prime/<name>, filenames_file ("a.jpg b.jpg" per line; the second token
         names both files, dataloader.py:148-149), pts1_file, gt_file (one np.savetxt row of 8 floats per pair)."""
 
-    def __init__(self, params, shuffle=True, device='cuda', seed=0, num_threads=20):
+    def __init__(self, params, shuffle=True, device='cuda', seed=0, num_threads=20, num_workers=0):
         self.params = params
         self.shuffle = shuffle
         self.device = torch.device(device)
+        self.num_workers = int(num_workers)         # > 0: decode in that many worker processes (stream() only)
         self.names, self.pts1, self.gt = read_img_and_gt(params.filenames_file, params.pts1_file, params.gt_file)
         if len(self.names) != len(self.pts1) or (self.gt is not None and len(self.gt) != len(self.names)):
             raise ValueError('filenames / pts1 / gt files disagree on the number of pairs')
@@ -141,10 +146,14 @@ class Dataloader(object):
         return torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
 
     def _batch(self, ids):
-        pr = self.params
         frames = list(self.pool.map(self._load, ids))
         I8 = torch.from_numpy(np.stack([f[0] for f in frames])).to(self.device, non_blocking=True)
         Ip8 = torch.from_numpy(np.stack([f[1] for f in frames])).to(self.device, non_blocking=True)
+        return self._finish(I8, Ip8, ids)
+
+    def _finish(self, I8, Ip8, ids):
+        """decoded uint8 frames on the device -> the model's input tensors (uh_prepare_inputs)"""
+        pr = self.params
         pts1 = torch.from_numpy(self.pts1[ids].astype(np.float32))
         aug = sample_augmentation(len(ids), pr.mode, pr.do_augment, self.gen) if pr.do_augment > 0 else None
         normalize = 'normalize' in pr.augment_list
@@ -165,18 +174,96 @@ class Dataloader(object):
             raise ValueError('Dataloader: %s lists no pairs' % self.params.filenames_file)
         if B <= 0:
             raise ValueError('Dataloader: batch_size must be positive')
+        gen = self._worker_stream(max(int(prefetch), 1) + 1) if self.num_workers > 0 else self._sync_stream()
         if prefetch > 0:
-            return self._prefetched(self._sync_stream(), int(prefetch))
-        return self._sync_stream()
+            return self._prefetched(gen, int(prefetch))
+        return gen
 
-    def _sync_stream(self):
+    def _id_batches(self):
         B = self.params.batch_size
         pending = []
         while True:
             while len(pending) < B:
                 pending.extend(self._order())
             ids, pending = pending[:B], pending[B:]
+            yield ids
+
+    def _sync_stream(self):
+        for ids in self._id_batches():
             yield self._batch(ids)
+
+    def _worker_stream(self, nbuf):
+        """Same batches, same order as _sync_stream, decoded by `num_workers` processes: up to `nbuf` batches are in flight
+        in the workers while the oldest one is uploaded and turned into the model's inputs."""
+        import subprocess
+        import sys
+        import tempfile
+        pr = self.params
+        B, H, W = pr.batch_size, pr.img_h, pr.img_w
+        per = 2 * B                                             # frames of one batch: I then I'
+        slots = nbuf * per
+        shm_dir = '/dev/shm' if os.path.isdir('/dev/shm') else None
+        fd, path = tempfile.mkstemp(prefix='uh_frames_', dir=shm_dir)
+        os.ftruncate(fd, slots * H * W * 3)
+        os.close(fd)
+        frames = np.memmap(path, dtype=np.uint8, mode='r+', shape=(nbuf, 2, B, H, W, 3))
+        script = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_worker.py')
+        K = self.num_workers
+        procs = [subprocess.Popen([sys.executable, script, path, str(slots), str(H), str(W)], stdin=subprocess.PIPE,
+                                  stdout=subprocess.PIPE, text=True, bufsize=1) for _ in range(K)]
+        try:
+            ids_iter = self._id_batches()
+            inflight = []                                        # (buffer index, ids, frames handed to each worker)
+            free = list(range(nbuf))
+            rr = 0
+
+            def submit():
+                nonlocal rr
+                buf = free.pop()
+                ids = next(ids_iter)
+                count = [0] * K
+                for which, sub in ((0, 'I'), (1, 'I_prime')):
+                    for j, i in enumerate(ids):
+                        name = self.names[i][1] if len(self.names[i]) > 1 else self.names[i][0]
+                        w = rr % K; rr += 1
+                        procs[w].stdin.write('%d %s\n' % (buf * per + which * B + j, os.path.join(pr.data_path, sub, name)))
+                        count[w] += 1
+                for p in procs:
+                    p.stdin.flush()
+                inflight.append((buf, ids, count))
+
+            while True:
+                while free:
+                    submit()
+                buf, ids, count = inflight.pop(0)
+                for w, n in enumerate(count):                    # every worker answers its lines in order
+                    for _ in range(n):
+                        ans = procs[w].stdout.readline()
+                        if not ans:
+                            raise RuntimeError('decode worker %d exited (code %s)' % (w, procs[w].poll()))
+                        if '!' in ans:
+                            raise RuntimeError('decode worker: ' + ans.strip())
+                # (pageable source: the copy has read the ring buffer when .to() returns, so the buffer can be re-used)
+                I8 = torch.from_numpy(frames[buf, 0]).to(self.device)
+                Ip8 = torch.from_numpy(frames[buf, 1]).to(self.device)
+                free.append(buf)
+                yield self._finish(I8, Ip8, ids)
+        finally:
+            for p in procs:
+                try:
+                    p.stdin.close()
+                except Exception:
+                    pass
+            for p in procs:
+                try:
+                    p.wait(timeout=5)
+                except Exception:
+                    p.kill()
+            del frames
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
 
     def _prefetched(self, gen, depth):
         import queue
@@ -203,6 +290,8 @@ class Dataloader(object):
                         return
             except BaseException as e:                        # delivered to the consumer, not swallowed
                 q.put((e, None))
+            finally:
+                gen.close()                                   # stops the decode workers / frees the frame ring, if any
 
         t = threading.Thread(target=producer, daemon=True)
         t.start()

@@ -89,6 +89,9 @@ def build_parser():
     p.add_argument('--data_pool', type=int, default=0,
                    help='> 0: pre-generate this many synthetic batches in HBM (118 MB each at 64 x 240x320: 288 GB holds '
                         'thousands) and cycle through them in a fresh random order per pass, instead of generating per step')
+    p.add_argument('--decode_workers', type=int, default=-1,
+                   help='--data_path: image-decode worker PROCESSES (dataloader.Dataloader(num_workers=...)); 0 = the 20-thread '
+                        'pool (interpreter-lock bound at ~2 000 pairs/s); -1 = min(48, host cores / 2)')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--log_every', type=int, default=100)
     p.add_argument('--save_every', type=int, default=1000)
@@ -306,7 +309,8 @@ def train(args):
                                         pts1_file=args.pts1_file, gt_file=args.gt_file, mode='train', batch_size=B_local,
                                         img_h=args.img_h, img_w=args.img_w, patch_size=args.patch_size,
                                         augment_list=args.augment_list, do_augment=args.do_augment)
-        loader = uh_data.Dataloader(prm, shuffle=True, device=device, seed=args.seed * 1000 + rank)
+        nw = args.decode_workers if args.decode_workers >= 0 else min(48, (os.cpu_count() or 2) // 2)
+        loader = uh_data.Dataloader(prm, shuffle=True, device=device, seed=args.seed * 1000 + rank, num_workers=nw)
 
         disk = loader.stream(prefetch=4)       # endless, never drops a pair, raises on an empty list; decode overlaps the step
     pool, order = [], []
