@@ -306,13 +306,13 @@ def test_tail_plan_reentry_constants_and_address_churn(pkg, dev):
         # of batches cycled by the trainer) is captured on its second sighting and replayed from then on
         c1 = plan.stats()['captures']
         for rep in range(4):
-            for Ui in held[:3]:
+            for Ui in held[-3:]:                                   # (run eagerly above: their first sighting)
                 x = h1.clone().requires_grad_(True)
                 li, pi, _, _ = ops.photometric_tail(batch['pts1'], x, Ui, batch['I2_aug'], batch['patch_indices'], P, graph=True)
                 li.backward()
                 assert torch.equal(pi, ref[0][1]) and torch.equal(x.grad, ref[0][3])
         side.synchronize()
-        assert 1 <= plan.stats()['captures'] - c1 <= 3, plan.stats()
+        assert plan.stats()['captures'] - c1 == 3, plan.stats()
 
 
 @pytest.mark.parametrize('kind', ['collapsed', 'overflow'])

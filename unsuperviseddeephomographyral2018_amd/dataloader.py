@@ -122,11 +122,16 @@ class Dataloader(object):
         self.params = params
         self.shuffle = shuffle
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.num_workers = int(num_workers)         # > 0: decode in that many worker processes (stream() only)
         self.names, self.pts1, self.gt = read_img_and_gt(params.filenames_file, params.pts1_file, params.gt_file)
         if len(self.names) != len(self.pts1) or (self.gt is not None and len(self.gt) != len(self.names)):
             raise ValueError('filenames / pts1 / gt files disagree on the number of pairs')
+        # two streams of randomness: the epoch permutations and the augmentation draws.  (One shared generator would tie
+        # the batches' contents to HOW FAR AHEAD the index list is consumed -- the worker-process route reads ahead.)
         self.gen = torch.Generator().manual_seed(seed)
+        self.gen_order = torch.Generator().manual_seed(seed + 0x5EED)
         self.pool = ThreadPoolExecutor(max_workers=num_threads)
         if 'per_image_normalize' in params.augment_list:
             raise NotImplementedError('per_image_normalize (the reference branch itself is broken, dataloader.py:180-187)')
@@ -143,7 +148,7 @@ class Dataloader(object):
 
     def _order(self):
         n = len(self.names)
-        return torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
+        return torch.randperm(n, generator=self.gen_order).tolist() if self.shuffle else list(range(n))
 
     def _batch(self, ids):
         frames = list(self.pool.map(self._load, ids))
@@ -273,13 +278,18 @@ class Dataloader(object):
 
         def producer():
             try:
+                side = None
                 if self.device.type == 'cuda':
                     torch.cuda.set_device(self.device)
+                    # uploads and uh_prepare_inputs run on a stream of their own, so that they overlap the training step
+                    # instead of queueing behind it on the default stream
+                    side = torch.cuda.Stream(device=self.device)
+                    torch.cuda.set_stream(side)               # (thread-local: only this producer thread)
                 for batch in gen:
                     ev = None
-                    if self.device.type == 'cuda':           # the consumer's stream waits for the producer's kernels
+                    if side is not None:                      # the consumer's stream waits for the producer's kernels
                         ev = torch.cuda.Event()
-                        ev.record(torch.cuda.current_stream(self.device))
+                        ev.record(side)
                     while not stop.is_set():
                         try:
                             q.put((batch, ev), timeout=0.1)
@@ -301,7 +311,11 @@ class Dataloader(object):
                 if isinstance(item, BaseException):
                     raise item
                 if ev is not None:
-                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    for t in item.values():                   # allocated on the producer's stream, consumed on this one
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)
                 yield item
         finally:
             stop.set()
