@@ -240,7 +240,7 @@ def warp_point(device, B, H, W, P, rho, iters=20, seed=7):
 
 def committed_traffic(key):
     """HBM bytes per launch from the committed PMC file (profiles/traffic_rNN.json) -- NOT measured in this run."""
-    for name in ('traffic_r02.json', 'traffic_r01.json'):
+    for name in ('traffic_r03.json', 'traffic_r02.json', 'traffic_r01.json'):
         f = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(f):
             try:
@@ -422,9 +422,8 @@ def main():
                               'uh_profile_*), inside the timed region', 'kernels': kern}
     # HBM bytes per launch of the dominant kernel from the PMC passes over THIS command (tools/gpu_traffic.sh ->
     # profiles/traffic_r01.json; FETCH_SIZE x2 KiB + WRITE_SIZE KiB, the gfx950 correction calibrated on a device copy)
-    traffic_file = os.path.join(ROOT, 'profiles', 'traffic_r02.json')
-    if not os.path.exists(traffic_file):
-        traffic_file = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
+    traffic_file = next((f for f in (os.path.join(ROOT, 'profiles', n) for n in ('traffic_r03.json', 'traffic_r02.json',
+                                                                               'traffic_r01.json')) if os.path.exists(f)), '')
     if dom is not None and os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
