@@ -129,3 +129,70 @@ def test_shard_and_lr_schedule():
     assert int(ds) == 58117
     assert staircase_lr(1e-4, 58116, ds) == 1e-4
     assert abs(staircase_lr(1e-4, 58117, ds) - 0.96e-4) < 1e-12
+
+
+def test_bench_launches_itself_for_more_than_one_gpu(monkeypatch):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE) must become the torchrun command of
+    the driver contract -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free> bench.py <same arguments>` -- instead of exiting; under a launcher (WORLD_SIZE set) it
+    must not re-launch."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('uh_bench_module', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    class Launched(Exception):
+        pass
+
+    def fake_execv(path, argv):
+        calls.append((path, list(argv)))
+        raise Launched()
+    monkeypatch.setattr(os, 'execv', fake_execv)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2'])
+    with pytest.raises(Launched):
+        bench.main()
+    path, argv = calls[0]
+    assert path == sys.executable and argv[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in argv and argv[argv.index('--nproc-per-node') + 1] == '4'
+    assert argv[argv.index('--master-addr') + 1] == '127.0.0.1' and int(argv[argv.index('--master-port') + 1]) > 0
+    k = argv.index(os.path.join(root, 'bench.py'))
+    assert argv[k + 1:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']
+    # already under a launcher: no re-launch -- the next thing main() does is join the process group
+    calls.clear()
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    from unsuperviseddeephomographyral2018_amd import dist as D
+
+    def joined():
+        raise Launched()
+    monkeypatch.setattr(D, 'init_from_env', joined)
+    with pytest.raises(Launched):
+        bench.main()
+    assert calls == []
+
+
+def test_backend_choice_follows_the_visible_devices(monkeypatch):
+    """dist.init_from_env picks gloo when the ranks cannot each have a GPU (no GPU here), honours UH_DIST_BACKEND, and does
+    not create a process group at world size 1."""
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    assert D.init_from_env() == (0, 1, 0) and not torch.distributed.is_initialized()
+    seen = {}
+    monkeypatch.setattr(torch.distributed, 'init_process_group', lambda backend, rank, world_size: seen.update(backend=backend, rank=rank, world=world_size))
+    monkeypatch.setenv('WORLD_SIZE', '2'); monkeypatch.setenv('RANK', '1'); monkeypatch.setenv('LOCAL_RANK', '1')
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)
+    D.init_from_env()
+    assert seen == {'backend': 'gloo', 'rank': 1, 'world': 2}
+    # two ranks, one visible GPU: RCCL needs a device per rank -> gloo; two GPUs -> nccl
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda d: None)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    D.init_from_env(); assert seen['backend'] == 'gloo'
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 2)
+    D.init_from_env(); assert seen['backend'] == 'nccl'
+    monkeypatch.setenv('UH_DIST_BACKEND', 'gloo')
+    D.init_from_env(); assert seen['backend'] == 'gloo'
