@@ -178,9 +178,9 @@ __device__ __forceinline__ void clip_pair(float v, float hi, float& c0, float& c
 //   ax1 = (x0f+1) - x      == 1 - ax0 bit for bit: both round the same real number 1 - frac(x)
 // and the four taps sit at oa, oa+pixB, oa+pitch, oa+pitch+pixB: ONE offset instead of four.
 struct Proj { float xs, ys, t, rt, x, y; };
-// project() in two halves, so that a kernel can test the eps-guard ONCE for all the pixels of a wave instead of paying
-// add + compare + select per pixel: project_rows() = theta @ grid without the guard, project_divide() = the rest, given
-// the guarded t.  |t| < 1e-7 is a measure-zero event; the kernels take a wave-uniform slow branch when any lane sees it.
+// project() in pieces, so that a kernel can test the eps-guard ONCE for all the pixels of a wave instead of paying
+// add + compare + select per pixel (project_all): guard_t() = the guard, project_divide() = everything after it, given xs,
+// ys and the guarded t.  |t| < 1e-7 is a measure-zero event; the kernels take a wave-uniform slow branch when any lane sees it.
 __device__ __forceinline__ float guard_t(float t) {
     return (fabsf(t) >= 1e-7f) ? t : t + 1e-6f;      // == t + 1e-6*(1 - [|t| >= 1e-7])        (:230-234)
 }
@@ -224,20 +224,8 @@ __device__ __forceinline__ Proj project(const Theta& th, float A0, float A3, flo
     Proj s;
     s.xs = (A0 + th.a[1] * gy) + th.a[2];                                                   // (:213)
     s.ys = (A3 + th.a[4] * gy) + th.a[5];
-    float t = (A6 + th.a[7] * gy) + th.a[8];
-    t = guard_t(t);
-    s.t = t;
-    const float y0 = __builtin_amdgcn_rcpf(t);
-    const float e0 = __builtin_fmaf(-t, y0, 1.0f);
-    const float y1 = __builtin_fmaf(e0, y0, y0);
-    s.rt = y1;
-    float q, r;
-    q = s.xs * y1; r = __builtin_fmaf(-t, q, s.xs); q = __builtin_fmaf(r, y1, q);
-    r = __builtin_fmaf(-t, q, s.xs); const float xn = __builtin_fmaf(r, y1, q);             // (:239)
-    q = s.ys * y1; r = __builtin_fmaf(-t, q, s.ys); q = __builtin_fmaf(r, y1, q);
-    r = __builtin_fmaf(-t, q, s.ys); const float yn = __builtin_fmaf(r, y1, q);             // (:240)
-    s.x = ((xn + 1.0f) * g.Wf) * 0.5f;               // /2 == *0.5 exactly                      (:97)
-    s.y = ((yn + 1.0f) * g.Hf) * 0.5f;                                                      // (:98)
+    s.t = guard_t((A6 + th.a[7] * gy) + th.a[8]);
+    project_divide(s, g);
     return s;
 }
 __device__ __forceinline__ Coord clip_coord(const Proj& p, const SrcGeom& g) {

@@ -91,7 +91,7 @@ def build_parser():
                         'thousands) and cycle through them in a fresh random order per pass, instead of generating per step')
     p.add_argument('--decode_workers', type=int, default=-1,
                    help='--data_path: image-decode worker PROCESSES (dataloader.Dataloader(num_workers=...)); 0 = the 20-thread '
-                        'pool (interpreter-lock bound at ~2 000 pairs/s); -1 = min(48, host cores / 2)')
+                        'pool (interpreter-lock bound at ~2 000 pairs/s); -1 = min(48, host cores / (2 x ranks)) per rank')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--log_every', type=int, default=100)
     p.add_argument('--save_every', type=int, default=1000)
@@ -309,7 +309,7 @@ def train(args):
                                         pts1_file=args.pts1_file, gt_file=args.gt_file, mode='train', batch_size=B_local,
                                         img_h=args.img_h, img_w=args.img_w, patch_size=args.patch_size,
                                         augment_list=args.augment_list, do_augment=args.do_augment)
-        nw = args.decode_workers if args.decode_workers >= 0 else min(48, (os.cpu_count() or 2) // 2)
+        nw = args.decode_workers if args.decode_workers >= 0 else min(48, (os.cpu_count() or 2) // (2 * world))   # per rank
         loader = uh_data.Dataloader(prm, shuffle=True, device=device, seed=args.seed * 1000 + rank, num_workers=nw)
 
         disk = loader.stream(prefetch=4)       # endless, never drops a pair, raises on an empty list; decode overlaps the step
@@ -346,12 +346,18 @@ def train(args):
         totals += cur
         window += cur
         win_n += 1
+        if step % args.log_every == 0:                       # every rank: its device's count of zeroed pairs, summed over ranks
+            z = _lib.dlt_zeroed_pairs(reset=True)            # (synchronous read of a device counter: log time only)
+            if world > 1:
+                zt = torch.tensor([z], dtype=torch.int64, device=device)
+                torch.distributed.all_reduce(zt)
+                z = int(zt.item())
+            zeroed_pairs += z
         if rank == 0 and step % args.log_every == 0:
             n = step - start_step + 1
             avg = (totals / n).tolist()                      # running means since the start, as the reference prints (:345-352)
             win = (window / win_n).tolist()                  # ... and the mean over the steps since the previous log line
             dt = time.time() - t0
-            zeroed_pairs += _lib.dlt_zeroed_pairs(reset=True)       # (synchronous read of a device counter: log time only)
             print('Train: step %d  ' % step + ', '.join('%s %.6f' % (k, v) for k, v in zip(names, avg))
                   + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
                   + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)])
