@@ -521,3 +521,32 @@ def test_default_model_path_gradient_values(pkg, dev, loss_type):
     print('default-path gradient: per-pair relative error', np.round(per_pair, 5), 'whole tensor', whole)
     assert np.median(per_pair) < 1e-4 and per_pair.max() < 5e-4, per_pair
     assert whole < 2e-4, whole
+
+
+def test_train_entry_point_from_generator_pool_and_disk(pkg, dev, tmp_path, capsys):
+    """homography_CNN_synthetic.train() end to end for a few steps on each input route: the generator in the loop, a
+    pre-generated pool, and the reference's on-disk layout through Dataloader with decode worker processes + prefetch.
+    Log lines carry the running means and pairs/s; a checkpoint is written and --resume continues from it."""
+    hm, synthetic, drv = pkg
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    common = ['--batch_size', '4', '--img_h', str(H), '--img_w', str(W), '--patch_size', str(P), '--rho', str(RHO),
+              '--loss_type', 'l1_loss', '--num_total_steps', '6', '--log_every', '2', '--save_every', '100',
+              '--model_dir', str(tmp_path / 'models')]
+    for extra in ([], ['--data_pool', '3']):
+        st = drv.train(drv.build_parser().parse_args(common + extra))
+        assert st.global_step == 6
+    out = capsys.readouterr().out
+    assert out.count('Train: step') == 6 and 'pairs/s' in out and 'l1_loss' in out
+    # on-disk route
+    b = synthetic.make_batch(12, H, W, P, RHO, seed=77, device=dev)
+    to_u8 = lambda t: (t * 50.0 + 128.0).clamp(0, 255).to(torch.uint8).cpu().numpy()
+    ff, fp, fg = dl.write_dataset(str(tmp_path / 'data') + '/', to_u8(b['I_aug']), to_u8(b['I_prime_aug']), b['pts1'].cpu().numpy(),
+                                  b['gt'].cpu().numpy(), fmt='jpg')
+    disk = ['--data_path', str(tmp_path / 'data') + '/', '--filenames_file', ff, '--pts1_file', fp, '--gt_file', fg]
+    for workers in ('0', '2'):
+        st = drv.train(drv.build_parser().parse_args(common + disk + ['--decode_workers', workers]))
+        assert st.global_step == 6 and all(torch.isfinite(p).all() for p in st.net.parameters())
+    st = drv.train(drv.build_parser().parse_args(common + ['--resume', 'True']))
+    assert st.global_step == 12                         # continued from the checkpoint of the previous run
+    out = capsys.readouterr().out
+    assert '===> Start step: 6' in out

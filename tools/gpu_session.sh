@@ -6,6 +6,7 @@
 #   smoke           __graft_entry__.smoke()
 #   bench           default bench line (+ fused-patch and raw-regressor lines with bench_extra)
 #   bench_extra     the two extra lines
+#   other           BASELINE configs[4] (supervised, batch 256) and the reference's default batch 128
 #   bench2          python bench.py --gpus 2 on ONE GPU over gloo (functional check of the N > 1 path and the self-launch)
 #   rocprof         rocprofv3 --kernel-trace --stats of the bench command + steady-state step breakdown
 #   rocprof_c4      the same of bench.py --only_points config4 (one shape per kernel name)
@@ -31,6 +32,8 @@ for ST in "$@"; do
     bench_extra)
             timeout 400 python bench.py --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --fused_patch 1 > gpurun_out/${TAG}_bench_line_fused_patch.json 2>/dev/null
             timeout 400 python bench.py --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --mid_training_theta 0 > gpurun_out/${TAG}_bench_line_raw_regressor.json 2>/dev/null ;;
+    other)  ( echo "== config 5: supervised 4-pt (reference flag h_loss), batch 256"; timeout 600 python bench.py --loss_type h_loss --per_gpu_batch 256 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 2>/dev/null | cut -c1-900
+              echo "== the reference's default batch 128, photometric l1"; timeout 600 python bench.py --per_gpu_batch 128 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 2>/dev/null | cut -c1-900 ) > gpurun_out/${TAG}_other_configs.txt; cut -c1-300 gpurun_out/${TAG}_other_configs.txt ;;
     bench2) UH_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --cpu_baseline 0 --quality 0 > gpurun_out/${TAG}_bench_line_2ranks_gloo_one_gpu.json 2> gpurun_out/${TAG}_bench_2ranks.err; cut -c1-400 gpurun_out/${TAG}_bench_line_2ranks_gloo_one_gpu.json ;;
     rocprof)
             ( cd /tmp && rm -rf /tmp/prof_$TAG && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench --output-format csv -- $BENCH > /root/repo/gpurun_out/${TAG}_bench_line_under_rocprof.json 2>/dev/null )
