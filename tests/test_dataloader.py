@@ -198,3 +198,61 @@ def test_worker_processes_and_prefetch_deliver_the_same_batches(tmp_path, uh_lib
             for _ in range(4):
                 next(it)
         it.close()
+
+
+def test_decode_worker_protocol(tmp_path):
+    """The decode worker process on its own (CPU): "slot path" lines in, frames in the shared uint8 ring, "slot" answers in
+    order; a missing file is answered as "slot !error", not with a crash; area-resize when the file's size differs."""
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, 'unsuperviseddeephomographyral2018_amd', '_decode_worker.py')
+    rs = np.random.RandomState(0)
+    imgs = [rs.randint(0, 256, (24, 32, 3)).astype(np.uint8) for _ in range(3)]
+    for i, a in enumerate(imgs):
+        Image.fromarray(a).save(str(tmp_path / ('%d.png' % i)))
+    Image.fromarray(rs.randint(0, 256, (48, 64, 3)).astype(np.uint8)).save(str(tmp_path / 'big.png'))
+    ring = str(tmp_path / 'ring.bin')
+    with open(ring, 'wb') as f:
+        f.truncate(5 * 24 * 32 * 3)
+    p = subprocess.Popen([sys.executable, script, ring, '5', '24', '32'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                         text=True, bufsize=1)
+    try:
+        for slot, name in ((2, '0.png'), (0, '1.png'), (3, '2.png'), (1, 'missing.png'), (4, 'big.png')):
+            p.stdin.write('%d %s\n' % (slot, str(tmp_path / name)))
+        p.stdin.flush()
+        ans = [p.stdout.readline().strip() for _ in range(5)]
+    finally:
+        p.stdin.close()
+        assert p.wait(timeout=20) == 0
+    assert ans[:3] == ['2', '0', '3'] and ans[3].startswith('1 !FileNotFoundError') and ans[4] == '4'
+    fr = np.memmap(ring, dtype=np.uint8, mode='r', shape=(5, 24, 32, 3))
+    assert np.array_equal(fr[2], imgs[0]) and np.array_equal(fr[0], imgs[1]) and np.array_equal(fr[3], imgs[2])
+    assert fr[4].std() > 0                                           # the 48x64 file arrived area-resized to 24x32
+
+
+def test_batch_order_does_not_depend_on_read_ahead(tmp_path, uh_lib_path):
+    """The epoch permutations and the augmentation draws come from two generators, so the sequence of index batches is the
+    same however far ahead it is consumed (the worker-process route reads several batches ahead of the augmentation)."""
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    N = 10
+    names = tmp_path / 'f.txt'; pts = tmp_path / 'p.txt'; gt = tmp_path / 'g.txt'
+    names.write_text(''.join('%d.png %d.png\n' % (i, i) for i in range(N)))
+    np.savetxt(str(pts), np.zeros((N, 8))); np.savetxt(str(gt), np.zeros((N, 8)))
+    prm = dl.dataloader_params(data_path=str(tmp_path), filenames_file=str(names), pts1_file=str(pts), gt_file=str(gt),
+                               mode='train', batch_size=4, img_h=8, img_w=8, patch_size=4, augment_list=['normalize'],
+                               do_augment=0.5)
+    a = dl.Dataloader(prm, shuffle=True, device='cpu', seed=3)
+    b = dl.Dataloader(prm, shuffle=True, device='cpu', seed=3)
+    ia, ib = a._id_batches(), b._id_batches()
+    seq_a = [next(ia) for _ in range(8)]                               # read ahead, no augmentation drawn in between
+    seq_b = []
+    for _ in range(8):
+        seq_b.append(next(ib))
+        dl.sample_augmentation(4, 'train', 0.5, b.gen)                # ... interleaved with augmentation draws
+    assert seq_a == seq_b
+    flat = [i for s in seq_a[:5] for i in s]
+    assert sorted(flat[:N]) == list(range(N))                         # the first epoch delivers every pair once
+    c = dl.Dataloader(prm, shuffle=True, device='cpu', seed=4)
+    assert [next(c._id_batches()) for _ in range(1)] != seq_a[:1]

@@ -207,7 +207,11 @@ class Dataloader(object):
         B, H, W = pr.batch_size, pr.img_h, pr.img_w
         per = 2 * B                                             # frames of one batch: I then I'
         slots = nbuf * per
-        shm_dir = '/dev/shm' if os.path.isdir('/dev/shm') else None
+        shm_dir = None                                          # frame ring: a tmpfs file if /dev/shm has the room, else $TMPDIR
+        if os.path.isdir('/dev/shm'):
+            fs = os.statvfs('/dev/shm')
+            if fs.f_bavail * fs.f_frsize > 2 * slots * H * W * 3:   # (a container's default /dev/shm is 64 MB: a write past
+                shm_dir = '/dev/shm'                                #  its capacity would kill the worker with SIGBUS)
         fd, path = tempfile.mkstemp(prefix='uh_frames_', dir=shm_dir)
         os.ftruncate(fd, slots * H * W * 3)
         os.close(fd)
