@@ -465,16 +465,25 @@ def main():
         except Exception:
             out['config']['rccl_version'] = None
         out['exchange'] = exchange
+    # The extra objects are measured after the headline and must not be able to lose it: a failure in one of them is
+    # reported in its place.
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:                              # noqa: BLE001 -- reported, not swallowed
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            return {'error': '%s: %s' % (type(e).__name__, e)}
     if world == 1 and args.north_star:
-        out['north_star_point'] = north_star_point(device, args)
+        out['north_star_point'] = guarded(north_star_point, device, args)
     if world == 1 and args.config4:
-        out['config4_point'] = config4_point(device, args)
+        out['config4_point'] = guarded(config4_point, device, args)
     if world == 1 and args.cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args, batch, step_fn.h4p_offset)
+        out['cpu_baseline'] = guarded(cpu_baseline, args, batch, step_fn.h4p_offset)
     if world == 1 and args.quality and args.loss_type == 'l1_loss':
         del step_fn, model
         torch.cuda.empty_cache()
-        out['quality'] = quality_run(device, args)
+        out['quality'] = guarded(quality_run, device, args)
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
