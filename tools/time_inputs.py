@@ -142,7 +142,7 @@ def main():
                                       img_h=H, img_w=W, patch_size=P, augment_list=['normalize'], do_augment=0.5)
             res = {'pairs_on_disk': n_pairs, 'write_seconds': round(t_write, 1),
                    'bytes_per_image': int(os.path.getsize(os.path.join(root, 'I', '0.' + fmt)))}
-            for pf, nw in ((0, 0), (4, 0), (4, 16), (4, 48)):
+            for pf, nw in ((0, 0), (4, 0), (4, 8), (4, 16), (4, 48)):
                 loader = D.Dataloader(prm, shuffle=True, device=dev, seed=1, num_workers=nw)
                 st = loader.stream(prefetch=pf)
                 for _ in range(3):

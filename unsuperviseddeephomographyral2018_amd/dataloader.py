@@ -216,6 +216,14 @@ class Dataloader(object):
         os.ftruncate(fd, slots * H * W * 3)
         os.close(fd)
         frames = np.memmap(path, dtype=np.uint8, mode='r+', shape=(nbuf, 2, B, H, W, 3))
+        # page-lock the ring so that the uploads are DMA copies that run beside the training step (a pageable source is
+        # staged through a bounce buffer by the calling thread); a refusal only means slower, synchronous uploads
+        pinned = False
+        if self.device.type == 'cuda':
+            try:
+                pinned = int(torch.cuda.cudart().cudaHostRegister(frames.ctypes.data, frames.nbytes, 0)) == 0
+            except Exception:
+                pinned = False
         script = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_worker.py')
         K = self.num_workers
         procs = [subprocess.Popen([sys.executable, script, path, str(slots), str(H), str(W)], stdin=subprocess.PIPE,
@@ -252,9 +260,11 @@ class Dataloader(object):
                             raise RuntimeError('decode worker %d exited (code %s)' % (w, procs[w].poll()))
                         if '!' in ans:
                             raise RuntimeError('decode worker: ' + ans.strip())
-                # (pageable source: the copy has read the ring buffer when .to() returns, so the buffer can be re-used)
-                I8 = torch.from_numpy(frames[buf, 0]).to(self.device)
-                Ip8 = torch.from_numpy(frames[buf, 1]).to(self.device)
+                I8 = torch.from_numpy(frames[buf, 0]).to(self.device, non_blocking=pinned)
+                Ip8 = torch.from_numpy(frames[buf, 1]).to(self.device, non_blocking=pinned)
+                if pinned:                                       # the ring slot is free again once the DMA has read it
+                    torch.cuda.current_stream(self.device).synchronize()
+                # (pageable source: the copy has read the ring buffer when .to() returns)
                 free.append(buf)
                 yield self._finish(I8, Ip8, ids)
         finally:
@@ -268,6 +278,11 @@ class Dataloader(object):
                     p.wait(timeout=5)
                 except Exception:
                     p.kill()
+            if pinned:
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(frames.ctypes.data)
+                except Exception:
+                    pass
             del frames
             try:
                 os.unlink(path)
