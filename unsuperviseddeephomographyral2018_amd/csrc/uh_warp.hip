@@ -85,7 +85,10 @@ static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the ste
                                   // (80 VGPRs, no spill; 6 blocks x 4 waves x 5 KiB LDS slices = 120 KiB of the CU's 160 KiB)
 #endif
 #ifndef UH_WARP_BWD_MINW
-#define UH_WARP_BWD_MINW 5        // 96 VGPRs without path C1 (no spill)
+#define UH_WARP_BWD_MINW 5        // 96 VGPRs without path C1 (no spill).  The instantiations that need more registers get one wave
+                                  // less instead of spilling (C = 4: 5 forward / 4 backward waves; the forward with `condition`: 5; the
+                                  // backward with dU, which holds four tap offsets per pixel for the scatter: 3) -- a spill is a
+                                  // scratch round trip per tile in a kernel that is short of memory slots, not of waves
 #endif
 static_assert(UH_WARP_STEPS_BWD % UH_WARP_BWD_BATCH == 0, "batch must divide the steps");
 constexpr int NWAVE = 4;                // waves per block, side by side in x: block tile = (4*TW) x TH
@@ -241,7 +244,7 @@ __device__ unsigned long long* g_trace = nullptr;
 
 // ------------------------------------------------------------------------------------------------
 template <int C, bool COND, bool SMALL>
-__global__ __launch_bounds__(256, UH_WARP_FWD_MINW) void warp_forward_kernel(
+__global__ __launch_bounds__(256, ((C == 4 || COND) ? UH_WARP_FWD_MINW - 1 : UH_WARP_FWD_MINW)) void warp_forward_kernel(
         const float* __restrict__ U, const float* __restrict__ theta, float* __restrict__ out,
         float* __restrict__ condition, int H, int W, int oh, int ow, float sx, float sy, int tiles_x, int tiles,
         unsigned nblk) {
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(256) void warp_backward_finish_kernel(const float* 
 }
 
 template <int C, bool WANT_DU, bool SMALL, bool PATCH = false>
-__global__ __launch_bounds__(256, UH_WARP_BWD_MINW) void warp_backward_kernel(
+__global__ __launch_bounds__(256, (WANT_DU ? 3 : (C == 4 ? UH_WARP_BWD_MINW - 1 : UH_WARP_BWD_MINW))) void warp_backward_kernel(
         const float* __restrict__ U, const float* __restrict__ theta, const float* __restrict__ dOut,
         float* __restrict__ partial, float* __restrict__ dU,
         int H, int W, int oh, int ow, float sx, float sy, int tiles_x, int tiles, unsigned nblk, PatchArgs pa) {
