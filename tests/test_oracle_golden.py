@@ -148,3 +148,18 @@ def test_patch_losses_oracle_vs_torch_ops():
     assert abs(float(torch.sqrt(((xt - yt) ** 2).mean())) - ref['rec_loss']) < 1e-12
     lx = torch.sqrt((xt ** 2).sum()); ly = torch.sqrt((yt ** 2).sum())
     assert abs(float(torch.sqrt(((yt / ly - xt / lx) ** 2).sum())) - ref['ncc_loss']) < 1e-12
+
+
+def test_division_by_three_without_a_divider_is_correctly_rounded():
+    """csrc/uh_warp.hip div_by_channels<3>: the sparse backward forms dPred/3 as q' = fma(fma(-3, q, a), y, q) with
+    y = RN(1/3), q = RN(a y) (Markstein's correction step) instead of the v_div_* sequence, and must equal the dense
+    chain's true division bit for bit.  Checked here for EVERY f32 mantissa (the sequence is invariant under scaling by
+    powers of two away from under/overflow), both signs, with the fused multiply-adds evaluated exactly in f64."""
+    m = np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3f800000)
+    for sign in (np.uint32(0), np.uint32(0x80000000)):
+        a = (m | sign).view(np.float32)
+        y = np.float32(1.0) / np.float32(3.0)
+        q = (a * y).astype(np.float32)
+        r = (a.astype(np.float64) - 3.0 * q.astype(np.float64)).astype(np.float32)          # fma(-3, q, a)
+        qq = (q.astype(np.float64) + r.astype(np.float64) * np.float64(y)).astype(np.float32)   # fma(r, y, q)
+        assert np.array_equal(qq, (a / np.float32(3.0)).astype(np.float32))
