@@ -330,6 +330,7 @@ def main():
     if args.mid_training_theta:
         g = torch.Generator(device=device).manual_seed(4321 + rank)
         step_fn.h4p_offset = batch['gt'] + 2.0 * torch.randn(B, 8, generator=g, device=device)
+    find_pass_s = step_fn.prime_conv_finds(batch)           # world > 1: MIOpen find by rank 0 first (untimed, before the warm-up)
     for _ in range(args.warmup):
         model = step_fn(batch)
     torch.cuda.synchronize(device)
@@ -458,12 +459,17 @@ def main():
     if other_law is not None and isinstance(out.get('roofline'), dict):
         out['roofline']['same_kernel_under_round1_law'] = other_law
     if world > 1:
-        out['config']['rccl_world_size'] = torch.distributed.get_world_size()
+        out['config']['world_size'] = torch.distributed.get_world_size()
         out['config']['dist_backend'] = torch.distributed.get_backend()
-        try:
-            out['config']['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:
-            out['config']['rccl_version'] = None
+        if out['config']['dist_backend'] == 'nccl':         # only a run that really went over RCCL says so
+            out['config']['rccl_world_size'] = torch.distributed.get_world_size()
+            try:
+                out['config']['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                out['config']['rccl_version'] = None
+        out['config']['conv_find_pass_s'] = round(find_pass_s, 1)
+        out['config']['conv_find_staggered'] = os.environ.get('UH_FIND_STAGGER', '1') != '0'
+        out['config']['model_rng'] = 'seed + rank per tower (independent dropout masks), variables broadcast from rank 0'
         out['exchange'] = exchange
     # The extra objects are measured after the headline and must not be able to lose it: a failure in one of them is
     # reported in its place.

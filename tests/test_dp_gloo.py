@@ -196,3 +196,36 @@ def test_backend_choice_follows_the_visible_devices(monkeypatch):
     D.init_from_env(); assert seen['backend'] == 'nccl'
     monkeypatch.setenv('UH_DIST_BACKEND', 'gloo')
     D.init_from_env(); assert seen['backend'] == 'gloo'
+
+
+def test_tower_rng_seed_gives_each_rank_its_own_dropout_stream():
+    """SURVEY 8e "Dropout RNG per rank": the reference builds one slim.dropout op per tower (homography_model.py:120-121,128)
+    => independent masks.  dist.seed_tower_rng(seed, rank) = seed + rank; the same rank re-seeded draws the same mask."""
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    import torch.nn.functional as F
+    x = torch.ones(4096)
+    assert D.seed_tower_rng(7, 0) == 7
+    m0 = F.dropout(x, 0.5, True)
+    assert D.seed_tower_rng(7, 1) == 8
+    m1 = F.dropout(x, 0.5, True)
+    D.seed_tower_rng(7, 1)
+    m1b = F.dropout(x, 0.5, True)
+    assert not torch.equal(m0, m1) and torch.equal(m1, m1b)
+    assert 0.45 < float(m0.ne(0).float().mean()) < 0.55
+
+
+def test_grad_averager_disabled_issues_no_collective():
+    """TrainStep.prime_conv_finds runs ONE rank's forward + backward while the others wait at a barrier: with
+    `enabled = False` the bucket hooks must not start an all-reduce (which would hang that lone rank)."""
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    torch.manual_seed(0)
+    net = Tiny()
+    avg = D.GradAverager(net, world=2)                 # claims two ranks; no process group exists -> any collective raises
+    avg.enabled = False
+    avg.reset()
+    net(torch.randn(4, 2, 8, 8)).sum().backward()
+    assert avg._handles == [] and all(b['pending'] == 0 for b in avg.buckets)
+    avg.enabled = True
+    avg.reset()
+    with pytest.raises(Exception):
+        net(torch.randn(4, 2, 8, 8)).sum().backward()  # enabled: the hook reaches for the (absent) process group

@@ -15,6 +15,10 @@
 #   micro:V1,V2     A/B/A/B microbench of the shipped library against lib/variants/libuh_V*.so (tools/variants.sh builds them)
 #   vtests:V[:K]    pytest -m gpu with UH_LIB_PATH = variant V
 #   inputs          section-8 f3 timing (tools/time_inputs.py)
+#   dp              tests/test_gpu_dp_product.py (2 gloo ranks on the one GPU: product DP step == one tower)
+#   bench8[:N]      python bench.py --gpus N (default 8) on ONE GPU over gloo, find pass staggered and not, cold MIOpen db each
+#   cold            tools/cold_forward.py (in-step forward: cold / warm x batch sweep x theta law)
+#   train_ref       tools/train_reference_schedule.sh (150 000 steps at the reference's schedule + test loop)
 #   trace:V         per-wave phase trace with the -DUH_WARP_TRACE variant V (tools/trace_waves.py)
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 TAG=$1; shift
@@ -64,6 +68,17 @@ for ST in "$@"; do
     trace)  UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py > gpurun_out/${TAG}_wave_trace_$A1.jsonl 2>gpurun_out/${TAG}_wave_trace.err
             UH_TRACE_BWD=1 UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py >> gpurun_out/${TAG}_wave_trace_$A1.jsonl 2>>gpurun_out/${TAG}_wave_trace.err
             cut -c1-1500 gpurun_out/${TAG}_wave_trace_$A1.jsonl ;;
+    dp)     timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=short > gpurun_out/${TAG}_pytest_dp_product.log 2>&1; grep -E "world 2|passed|failed|Error|error" gpurun_out/${TAG}_pytest_dp_product.log | tail -12 ;;
+    bench8) # `python bench.py --gpus 8` on ONE GPU: 8 gloo ranks (functional run of the N = 8 plumbing), wall time with the conv
+            # find pass staggered (rank 0 first; default) and not, each from a cold MIOpen user db
+            for SG in 1 0; do
+              rm -rf ~/.config/miopen ~/.cache/miopen; t0=$(date +%s.%N)
+              UH_FIND_STAGGER=$SG UH_DIST_BACKEND=gloo timeout 900 python bench.py --gpus ${A1:-8} --steps 5 --warmup 2 --cpu_baseline 0 --quality 0 > gpurun_out/${TAG}_bench_line_${A1:-8}ranks_gloo_one_gpu_stagger$SG.json 2> gpurun_out/${TAG}_bench_${A1:-8}ranks_stagger$SG.err
+              echo "rc $? stagger $SG wall $(python -c "import time;print(round(time.time()-$t0,1))") s" | tee -a gpurun_out/${TAG}_bench_${A1:-8}ranks_wall.txt
+              cut -c1-300 gpurun_out/${TAG}_bench_line_${A1:-8}ranks_gloo_one_gpu_stagger$SG.json; tail -3 gpurun_out/${TAG}_bench_${A1:-8}ranks_stagger$SG.err
+            done ;;
+    cold)   timeout 600 python tools/cold_forward.py --tag $TAG > gpurun_out/${TAG}_cold_forward.jsonl 2> gpurun_out/${TAG}_cold_forward.err; cat gpurun_out/${TAG}_cold_forward.jsonl | cut -c1-260; tail -3 gpurun_out/${TAG}_cold_forward.err ;;
+    train_ref) TAG=$TAG bash tools/train_reference_schedule.sh ;;
     *) echo "unknown stage $NAME" ;;
   esac
 done

@@ -47,6 +47,15 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def seed_tower_rng(seed, rank):
+    """Every tower draws its OWN dropout masks: the reference builds one slim.dropout op per tower
+    (homography_model.py:120-121,128, one model per tower at homography_CNN_synthetic.py:229-233), so the masks of two
+    towers are independent.  One process per GPU => seed the model RNG (host + every device generator) with seed + rank.
+    Call it AFTER the variables were created / broadcast, so that the initial variables stay rank-equal."""
+    torch.manual_seed(int(seed) + int(rank))
+    return int(seed) + int(rank)
+
+
 def shard(tensor, rank, world):
     """Contiguous batch shard of this rank -- tf.split(x, num_gpus, 0)[rank]."""
     B = tensor.shape[0]
@@ -71,6 +80,7 @@ class GradAverager(object):
         # gloo (CPU tests) has no AVG: SUM + div_.
         self._avg_in_collective = bool(self.world > 1 and dist.is_initialized() and dist.get_backend() == 'nccl')
         self._op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        self.enabled = True                # False: the hooks issue no collective (TrainStep.prime_conv_finds: one rank alone)
         self.exposed_wait_s = 0.0          # host time finish() spent blocked on the collectives (what backward did not hide)
         self.finishes = 0
         for plist in (b0, b1):
@@ -96,7 +106,7 @@ class GradAverager(object):
     def _make_hook(self, bucket):
         def hook(param):
             bucket['pending'] -= 1
-            if bucket['pending'] == 0 and self.world > 1:
+            if bucket['pending'] == 0 and self.world > 1 and self.enabled:
                 self._handles.append(dist.all_reduce(bucket['flat'], op=self._op, async_op=True))
         return hook
 

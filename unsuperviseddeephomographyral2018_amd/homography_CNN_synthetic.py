@@ -117,9 +117,13 @@ class TrainStep(object):
         self.world = world
         self.net = net if net is not None else VGGRegressor(args.patch_size, args.use_batch_norm)
         self.net = self.net.to(device).to(memory_format=torch.channels_last)
+        self.rank = torch.distributed.get_rank() if (world > 1 and torch.distributed.is_initialized()) else 0
         if world > 1:                                       # identical initial variables on every rank
             for t in list(self.net.parameters()) + list(self.net.buffers()):
                 torch.distributed.broadcast(t.data, src=0)
+            # ... and independent dropout masks per tower, as the reference's one-dropout-op-per-tower graph draws them
+            # (homography_model.py:120-121,128; SURVEY 8e "Dropout RNG per rank").  World size 1 keeps the caller's seed.
+            self.model_rng_seed = uh_dist.seed_tower_rng(getattr(args, 'seed', 0), self.rank)
         self.decay_steps = decay_steps_for(args.lr, args.min_lr)
         self.global_step = 0
         # world == 1: no exchange step -> no flat buckets: autograd hands each parameter its gradient directly (no
@@ -208,6 +212,42 @@ class TrainStep(object):
         else:
             self.opt.zero_grad(set_to_none=True)
 
+    def prime_conv_finds(self, batch):
+        """World > 1, before the first step: rank 0 ALONE runs one forward + backward (no collective, no optimizer step)
+        so that MIOpen's find mode (torch.backends.cudnn.benchmark: ~24 conv problems, tens of seconds of kernel builds)
+        happens ONCE and lands in the user find-db / kernel cache; the other ranks run the same pass after a barrier and hit
+        what rank 0 stored.  N concurrent finds all build the same kernels and contend for one sqlite kernel cache and one
+        find-db file.  UH_FIND_STAGGER=0 switches the staggering off (every rank primes at once).  Gradients are discarded;
+        every rank draws one step's worth of dropout masks."""
+        if self.world == 1:
+            return 0.0
+        stagger = os.environ.get('UH_FIND_STAGGER', '1') != '0'
+        t0 = time.perf_counter()
+
+        def one_pass():
+            self.averager.enabled = False
+            try:
+                self.averager.reset()
+                model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
+                                        net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
+                                        h4p_offset=self.h4p_offset, zero_nonfinite_grad=self._zero_nonfinite())
+                model.loss.backward()
+                if self.device.type == 'cuda':
+                    torch.cuda.synchronize(self.device)
+            finally:
+                self.averager.enabled = True
+                self.averager.reset()
+        if stagger:
+            if self.rank == 0:
+                one_pass()
+            torch.distributed.barrier()
+            if self.rank != 0:
+                one_pass()
+        else:
+            one_pass()
+        torch.distributed.barrier()
+        return time.perf_counter() - t0
+
     def _forward_backward_update(self, batch):
         self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
@@ -274,6 +314,9 @@ class TrainStep(object):
             if torch.is_tensor(st.get('step')) and self.device.type == 'cuda':
                 st['step'] = st['step'].to(device=self.device, dtype=torch.float32)
         self.global_step = 0 if retrain else sd['global_step']        # (:314-317)
+        # a step graph captured BEFORE this call replays against the old lr / state tensors: capture again on the next step
+        self._graph = None
+        self._static = None
 
 
 def _ckpt_path(args):
@@ -320,6 +363,12 @@ def train(args):
                                      seed=args.seed + i * world + rank, device=device, kind=args.texture)
                 for i in range(args.data_pool)]
         pool_gen = torch.Generator().manual_seed(args.seed * 7919 + rank)
+    if world > 1:
+        # MIOpen find mode once, by rank 0, before anyone steps (TrainStep.prime_conv_finds); any batch of the step's shape does
+        t_find = step_fn.prime_conv_finds(synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
+                                                               seed=args.seed + rank, device=device, kind=args.texture))
+        if rank == 0:
+            print('===> conv find pass (rank 0 first, then the others): %.1f s' % t_find, flush=True)
     window = torch.zeros(len(names), device=device)
     win_n = 0
     nonfinite_steps = torch.zeros((), device=device)
@@ -436,11 +485,13 @@ class TestHomography(object):
         res = {
             'mean_corner_error': total_bounded / num_steps,
             'fail_percent': 100.0 * total_fail / (num_steps * a.batch_size),
-            'percentiles': {q: float(np.percentile(per_pair, q)) for q in (30, 60, 100)},
+            'percentiles': {q: float(np.percentile(per_pair, q)) for q in (20, 30, 50, 60, 80, 100)},   # (:577-579)
             'num_pairs': int(per_pair.size),
         }
         print('====> Result for RHO:', a.rho, ' loss ', a.loss_type)
         print('|Average error: %.4f |Fail percent: %.3f' % (res['mean_corner_error'], res['fail_percent']))
+        print('===> Percentile Values (per-pair corner RMSE, px): ' + ', '.join(
+            '%d%%: %.3f' % (q, v) for q, v in sorted(res['percentiles'].items())) + '  over %d pairs' % res['num_pairs'])
         return res
 
 

@@ -57,8 +57,10 @@ class VGGRegressor(nn.Module):
     weights, zero biases.  Optional BN keeps the reference's quirk: is_training is passed as the
     *decay* (:93), i.e. decay=1 -> moving statistics never move (momentum 0 here)."""
 
-    def __init__(self, patch_size=128, use_batch_norm=False, fused_epilogue=True):
+    def __init__(self, patch_size=128, use_batch_norm=False, fused_epilogue=True, dropout_p=0.5):
         super().__init__()
+        # slim.dropout keep_prob 0.5 (:120-121,128); a test that compares two ways of computing ONE gradient sets 0
+        self.dropout_p = dropout_p
         # conv GEMMs on stock MIOpen; bias + ReLU (+ their backward and the bias gradient) as one HIP pass each
         self.fused_epilogue = fused_epilogue
         chans = [(2, 64), (64, 64), (64, 64), (64, 64), (64, 128), (128, 128), (128, 128), (128, 128)]
@@ -99,9 +101,9 @@ class VGGRegressor(nn.Module):
         x = self._conv_pool(self._conv(x, 2), 3)
         x = self._conv_pool(self._conv(x, 4), 5)
         x = self._conv(self._conv(x, 6), 7)
-        x = F.dropout(x, 0.5, self.training)
+        x = F.dropout(x, self.dropout_p, self.training)
         x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)          # slim.flatten of NHWC
-        x = F.dropout(F.relu(self.fc1(x)), 0.5, self.training)
+        x = F.dropout(F.relu(self.fc1(x)), self.dropout_p, self.training)
         return self.fc2(x)
 
 
