@@ -93,7 +93,8 @@ UH_API int uh_dlt_backward(const float* pts1, const float* h4p, const float* H,
 
 /* How many pairs UH_DLT_ZERO_NONFINITE_GRAD has zeroed on the current device since the last reset (the one deliberate
  * departure from the reference, which lets tf.matrix_solve's NaN through, homography_model.py:242: the trainer prints
- * this so that the guard is never silent).  Synchronous: waits for the device; reset != 0 clears the counter.        */
+ * this so that the guard is never silent).  Synchronous: waits for the whole device (every stream), then takes the count
+ * -- and with reset != 0 clears it -- in one atomic exchange: no increment is lost between the read and the clear.   */
 UH_API int uh_dlt_zeroed_pairs(unsigned long long* count, int reset);
 
 /* ---- Spatial transformer ----------------------------------------------------------------------

@@ -222,6 +222,7 @@ def test_decode_worker_protocol(tmp_path):
         for slot, name in ((2, '0.png'), (0, '1.png'), (3, '2.png'), (1, 'missing.png'), (4, 'big.png')):
             p.stdin.write('%d %s\n' % (slot, str(tmp_path / name)))
         p.stdin.flush()
+        assert p.stdout.readline().strip() == 'ready'              # greeting: the ring is mapped (the parent unlinks it then)
         ans = [p.stdout.readline().strip() for _ in range(5)]
     finally:
         p.stdin.close()
@@ -256,3 +257,85 @@ def test_batch_order_does_not_depend_on_read_ahead(tmp_path, uh_lib_path):
     assert sorted(flat[:N]) == list(range(N))                         # the first epoch delivers every pair once
     c = dl.Dataloader(prm, shuffle=True, device='cpu', seed=4)
     assert [next(c._id_batches()) for _ in range(1)] != seq_a[:1]
+
+
+def _write_tiny_dataset(tmp_path, n, H, W, with_images=True):
+    from PIL import Image
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    rs = np.random.RandomState(1)
+    I = rs.randint(0, 256, (n if with_images else 0, H, W, 3)).astype(np.uint8)
+    pts1 = np.tile(np.array([[4, 4, 12, 4, 12, 12, 4, 12]], np.float32), (n, 1)); gt = np.zeros((n, 8), np.float32)
+    root = str(tmp_path / ('a_rather_long_directory_name_' * 3))
+    if with_images:
+        ff, fp, fg = dl.write_dataset(root, I, I, pts1, gt, fmt='png')
+    else:
+        os.makedirs(root, exist_ok=True)
+        ff, fp, fg = (os.path.join(root, f) for f in ('filenames.txt', 'pts1.txt', 'gt.txt'))
+        with open(ff, 'w') as f:
+            f.writelines('%d.png %d.png\n' % (i, i) for i in range(n))
+        np.savetxt(fp, pts1); np.savetxt(fg, gt)
+    prm = dl.dataloader_params(data_path=root, filenames_file=ff, pts1_file=fp, gt_file=fg, mode='train', batch_size=n,
+                               img_h=H, img_w=W, patch_size=8, augment_list=['normalize'], do_augment=0.0)
+    return dl, prm, I
+
+
+def _rings():
+    import glob
+    import tempfile
+    return set(glob.glob('/dev/shm/uh_frames_*')) | set(glob.glob(os.path.join(tempfile.gettempdir(), 'uh_frames_*')))
+
+
+@pytest.mark.timeout(180)
+def test_worker_stream_leaves_no_frame_ring_behind_and_stops_its_producer(tmp_path):
+    """the /dev/shm frame ring of Dataloader(num_workers=K) outlived the process -- cleanup sat in the
+    `finally` of a daemon producer thread nobody joined.  Now the file is unlinked as soon as every worker has mapped it
+    (nothing to leak, whatever happens later), and closing the prefetched stream ends the producer thread and the worker
+    processes.  CPU: uh_prepare_inputs (the only device work) is replaced by a stand-in."""
+    import threading
+    dl, prm, I = _write_tiny_dataset(tmp_path, 6, 16, 24)
+    before = _rings()
+    n_threads = threading.active_count()
+    loader = dl.Dataloader(prm, shuffle=False, device='cpu', num_workers=2)
+    loader._finish = lambda I8, Ip8, ids: {'I8': I8.clone(), 'ids': list(ids)}
+    it = loader.stream(prefetch=3)
+    got = [next(it) for _ in range(4)]
+    assert _rings() == before                                   # already gone while the stream is live
+    for b in got:
+        assert np.array_equal(b['I8'].numpy(), I[b['ids']])    # ... and the mapping still carries the frames
+    it.close()
+    assert _rings() == before
+    for _ in range(100):                                        # producer + per-worker reader threads are gone
+        if threading.active_count() <= n_threads:
+            break
+        import time
+        time.sleep(0.05)
+    assert threading.active_count() <= n_threads
+    # dropped without close(): the generator's finalizer does the same
+    it2 = loader.stream(prefetch=2)
+    next(it2)
+    del it2
+    import gc
+    gc.collect()
+    assert _rings() == before
+
+
+@pytest.mark.timeout(120)
+def test_worker_errors_raise_instead_of_deadlocking(tmp_path):
+    """one worker, a big batch, several batches in flight and EVERY file missing -- the error answers
+    (~100 KB) overflow the worker's 64 KB stdout pipe while the parent is still writing paths.  Must raise the worker's
+    error, not hang; "!" inside a path is not an error marker."""
+    dl, prm, _ = _write_tiny_dataset(tmp_path, 128, 16, 24, with_images=False)
+    loader = dl.Dataloader(prm, shuffle=False, device='cpu', num_workers=1)
+    loader._finish = lambda I8, Ip8, ids: {'ids': list(ids)}
+    before = _rings()
+    with pytest.raises(RuntimeError, match='decode worker: .*FileNotFoundError'):
+        next(loader.stream(prefetch=4))
+    assert _rings() == before
+    # a "!" in a file NAME is data, not an error
+    dl2, prm2, I = _write_tiny_dataset(tmp_path / 'wow!', 4, 16, 24)
+    loader2 = dl2.Dataloader(prm2, shuffle=False, device='cpu', num_workers=1)
+    loader2._finish = lambda I8, Ip8, ids: {'I8': I8.clone(), 'ids': list(ids)}
+    it = loader2.stream()
+    b = next(it)
+    assert np.array_equal(b['I8'].numpy(), I[b['ids']])
+    it.close()

@@ -313,6 +313,18 @@ def test_tail_plan_reentry_constants_and_address_churn(pkg, dev):
                 assert torch.equal(pi, ref[0][1]) and torch.equal(x.grad, ref[0][3])
         side.synchronize()
         assert plan.stats()['captures'] - c1 == 3, plan.stats()
+        # (5) ... nor does a cycle LONGER than the old 8-entry cache thrash it: 12 sets cycled four times are
+        # captured once each (second sighting) and replayed afterwards -- not re-captured and evicted on every step
+        c2 = plan.stats()['captures']
+        for rep in range(4):
+            for Ui in held[:12]:
+                x = h1.clone().requires_grad_(True)
+                li, pi, _, _ = ops.photometric_tail(batch['pts1'], x, Ui, batch['I2_aug'], batch['patch_indices'], P, graph=True)
+                assert torch.equal(pi, ref[0][1])
+            side.synchronize()
+            if rep == 1:
+                c3 = plan.stats()['captures']
+        assert plan.stats()['captures'] - c2 <= 12 and plan.stats()['captures'] == c3, (c2, c3, plan.stats())
 
 
 @pytest.mark.parametrize('kind', ['collapsed', 'overflow'])

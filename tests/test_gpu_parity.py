@@ -295,11 +295,13 @@ def test_config4_backward_vs_oracle(ops, dev, kind):
     assert relerr(got[2], ref[2]) < 2e-4                       # the well-conditioned image, plain relative error
 
 
-def test_warp_backward_dU_large_and_far_field(ops, dev):
+@pytest.mark.parametrize('C', [3, 1, 2, 4])
+def test_warp_backward_dU_large_and_far_field(ops, dev, C):
     """dU (the library's only float-atomic path) at 240x320 on the benchmark law, a far-field theta and a theta that
-    collapses corner pairs on the border."""
-    rs = np.random.RandomState(19)
-    B, H, W, C = 3, 240, 320, 3
+    collapses corner pairs on the border -- for every channel count: warp_backward_kernel<C, WANT_DU=true, ...> are four
+    differently budgeted instantiations (98 / 118 / 138 / 158 VGPRs, 3 waves per SIMD; tests/test_kernel_resources.py)."""
+    rs = np.random.RandomState(19 + (C if C != 3 else 0))
+    B, H, W = 3, 240, 320
     d = O.synthetic_batch(3, 1, H=H, W=W, P=128, rho=45)
     U = rs.randn(B, H, W, C).astype(np.float32)
     th0 = O.theta_from_H(O.solve_dlt_lapack64(d['pts1'], d['pred_h4p']), W, H, np.float64).reshape(3, 3)
@@ -710,11 +712,14 @@ def _large_inputs(B=3, H=1200, W=1200, C=3, seed=5):
     return rs, U, theta
 
 
-def test_large_image_backward_dense_vs_oracle(ops, dev):
-    """warp_backward_kernel<C, *, SMALL=false>: dTheta (and dU) of a 1200x1200x3 source against the f64 closed form at the
-    f32 sample positions; out_size != (H, W) keeps the oracle fast and covers the backward with a resampled output."""
-    rs, U, theta = _large_inputs()
+@pytest.mark.parametrize('C,side', [(3, 1200), (1, 2100), (2, 1500), (4, 1100)])
+def test_large_image_backward_dense_vs_oracle(ops, dev, C, side):
+    """warp_backward_kernel<C, *, SMALL=false>: dTheta (and dU) of a source frame beyond 2^24 bytes (1200x1200x3, 2100x2100x1,
+    1500x1500x2, 1100x1100x4) against the f64 closed form at the f32 sample positions; out_size != (H, W) keeps the oracle
+    fast and covers the backward with a resampled output.  Staged, gather and clipped thetas (_large_inputs)."""
+    rs, U, theta = _large_inputs(H=side, W=side, C=C)
     B, H, W, C = U.shape
+    assert H * W * C * 4 > (1 << 24)
     oh, ow = 200, 264
     g = rs.randn(B, oh, ow, C).astype(np.float32)
     Ut = T(U, dev).requires_grad_(True); tt = T(theta, dev).requires_grad_(True)
@@ -774,7 +779,7 @@ def test_large_image_sparse_backward_and_fused_patch(ops, dev):
     assert_same_bits(pa[:1].detach().cpu().numpy(), gray, 'large image pred_I2')
 
 
-@pytest.mark.parametrize('C', [1, 3])
+@pytest.mark.parametrize('C', [1, 2, 3, 4])
 @pytest.mark.parametrize('shape', [(3, 20, 30, 41, 70), (2, 64, 64, 16, 200), (2, 97, 45, 130, 33)])
 def test_warp_backward_out_size_differs_from_input(ops, dev, C, shape):
     """Backward with out_size != (H, W) (ragged, up- and down-sampled): dTheta and dU vs the f64 closed form."""

@@ -3,7 +3,8 @@
 The reference decodes inside TF queue runners -- native threads (dataloader.py:230-246).  Python threads share one
 interpreter lock around PIL's non-decoding work, which caps a thread pool at ~4 images/ms whatever the core count, so
 the loader can start K of these instead: plain `python -m ..._decode_worker <frames file> <slots> <img_h> <img_w>`
-children (they import numpy + PIL only, never torch / HIP) that read "slot<space>path" lines on stdin, decode the file
+children (they import numpy + PIL only, never torch / HIP) that say "ready" once the ring is mapped (the parent then
+unlinks the file: nothing is left behind whatever happens to either side), read "slot<space>path" lines on stdin, decode the file
 (area-resize to img_h x img_w if needed, as `dataloader._decode`) straight into slot `slot` of a uint8
 [slots, img_h, img_w, 3] array memory-mapped from a file under /dev/shm, and answer "slot" (or "slot !message") on stdout.
 """
@@ -17,6 +18,8 @@ def main(argv):
     from PIL import Image
     frames = np.memmap(path, dtype=np.uint8, mode='r+', shape=(slots, img_h, img_w, 3))
     out = sys.stdout
+    out.write('ready\n')                          # the ring is mapped: the parent may unlink the file now
+    out.flush()
     for line in sys.stdin:
         line = line.rstrip('\n')
         if not line:
@@ -30,7 +33,7 @@ def main(argv):
                 frames[int(slot)] = np.asarray(im, dtype=np.uint8)
             out.write(slot + '\n')
         except Exception as e:                      # reported to the parent, which raises
-            out.write('%s !%s: %s\n' % (slot, type(e).__name__, str(e).replace('\n', ' ')))
+            out.write('%s !%s: %s\n' % (slot, type(e).__name__, str(e).replace('\n', ' ')[:300]))
         out.flush()
 
 

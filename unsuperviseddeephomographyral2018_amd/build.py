@@ -53,5 +53,59 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+def kernel_resources(force=False):
+    """Register / LDS / scratch budget of EVERY kernel of the library, from the code-object metadata hipcc emits
+    (`-S --cuda-device-only`: device assembly only, ~10 s for uh_warp.hip, the files in parallel), cached beside the library
+    under the same source fingerprint.  -> {demangled kernel name: {'file', 'vgpr', 'agpr', 'sgpr', 'vgpr_spill', 'sgpr_spill',
+    'scratch_bytes', 'lds_bytes', 'dynamic_stack', 'max_threads'}}.  tests/test_kernel_resources.py holds the budgets."""
+    import json
+    import re
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    import yaml
+    os.makedirs(LIBDIR, exist_ok=True)
+    cache = os.path.join(LIBDIR, 'kernel_resources.json')
+    fp = _fingerprint()
+    if not force and os.path.exists(cache):
+        try:
+            with open(cache) as fh:
+                c = json.load(fh)
+            if c.get('fingerprint') == fp:
+                return c['kernels']
+        except Exception:
+            pass
+    dev_flags = [f for f in FLAGS if f not in ('-shared', '-fPIC')] + ['-S', '--cuda-device-only', '-Wno-unused-command-line-argument']
+    hipcc = find_hipcc()
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        def one(src):
+            asm = os.path.join(td, src + '.s')
+            res = subprocess.run([hipcc] + dev_flags + [os.path.join(CSRC, src), '-o', asm], capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError('hipcc -S failed for %s:\n%s%s' % (src, res.stdout, res.stderr))
+            with open(asm) as fh:
+                text = fh.read()
+            m = re.search(r'\.amdgpu_metadata\n---\n(.*?)\n\.\.\.\n', text, re.S)
+            return src, (yaml.safe_load(m.group(1)).get('amdhsa.kernels', []) if m else [])
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            per_file = list(ex.map(one, SOURCES))
+    names = [k['.name'] for _, ks in per_file for k in ks]
+    filt = shutil.which('c++filt')
+    dem = subprocess.run([filt] + names, capture_output=True, text=True).stdout.split('\n') if (filt and names) else names
+    i = 0
+    for src, ks in per_file:
+        for k in ks:
+            name = re.sub(r'\(.*$', '', dem[i]).replace('void ', '') or k['.name']
+            i += 1
+            out[name] = {'file': src, 'vgpr': k['.vgpr_count'], 'agpr': k.get('.agpr_count', 0), 'sgpr': k['.sgpr_count'],
+                         'vgpr_spill': k['.vgpr_spill_count'], 'sgpr_spill': k['.sgpr_spill_count'],
+                         'scratch_bytes': k['.private_segment_fixed_size'], 'lds_bytes': k['.group_segment_fixed_size'],
+                         'dynamic_stack': bool(k.get('.uses_dynamic_stack', False)),
+                         'max_threads': k.get('.max_flat_workgroup_size')}
+    with open(cache, 'w') as fh:
+        json.dump({'fingerprint': fp, 'kernels': out}, fh, indent=0, sort_keys=True)
+    return out
+
+
 if __name__ == '__main__':
     print(build_library(force=True, verbose=True))

@@ -121,6 +121,11 @@ __global__ __launch_bounds__(256) void dlt_forward_kernel(const float* __restric
 
 // pairs whose gradient UH_DLT_ZERO_NONFINITE_GRAD zeroed since the last reset, on this device (uh_dlt_zeroed_pairs)
 __device__ unsigned long long g_dlt_zeroed_pairs = 0ull;
+__device__ unsigned long long g_dlt_zeroed_taken = 0ull;
+// read (and clear) the counter in ONE atomic: an increment can never fall between a read and a separate write of zero
+__global__ void dlt_take_zeroed_kernel(int reset) {
+    g_dlt_zeroed_taken = reset ? atomicExch(&g_dlt_zeroed_pairs, 0ull) : atomicAdd(&g_dlt_zeroed_pairs, 0ull);
+}
 
 // Backward: g_b = A^-T g_h (tf MatrixSolveGrad: matrix_solve(A, grad, adjoint=True), i.e. an LU of
 // A^T), g_A = -g_b h^T; only columns 6,7 of A and the rhs depend on p2 = pts1 + h4p, so
@@ -223,13 +228,16 @@ extern "C" int uh_dlt_backward(const float* pts1, const float* h4p, const float*
 }
 
 extern "C" int uh_dlt_zeroed_pairs(unsigned long long* count, int reset) {
-    // synchronous (waits for the device): call it at log time, never inside a stream capture
+    // synchronous: call it at log time, never inside a stream capture.  hipDeviceSynchronize first, so that kernels already
+    // enqueued on ANY stream -- also hipStreamNonBlocking ones, which the NULL stream does not order against -- are counted;
+    // then one atomicExch takes and clears the counter (pairs zeroed by launches racing with this call are simply counted by
+    // the next one: nothing is lost, nothing is counted twice)
     if (!count) return UH_E_NULL;
-    hipError_t e = hipMemcpyFromSymbol(count, HIP_SYMBOL(uh::g_dlt_zeroed_pairs), sizeof(*count));
+    hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return (int)e;
-    if (reset) {
-        const unsigned long long z = 0ull;
-        e = hipMemcpyToSymbol(HIP_SYMBOL(uh::g_dlt_zeroed_pairs), &z, sizeof(z));
-    }
+    hipLaunchKernelGGL(uh::dlt_take_zeroed_kernel, dim3(1), dim3(1), 0, (hipStream_t)0, reset ? 1 : 0);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyFromSymbol(count, HIP_SYMBOL(uh::g_dlt_zeroed_taken), sizeof(*count));
     return (int)e;
 }

@@ -160,7 +160,10 @@ extern "C" int uh_tail_run(uh_tail_plan* p, const float* pts1, const float* h4p,
     hipGraphExec_t exec = nullptr;
     he = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (he != hipSuccess) { (void)hipGraphDestroy(graph); return (int)he; }
-    if (p->cache.size() >= 8) {                      // evict the least recently used instance
+    // The cache is as large as the `seen` ring: every set that can be recognised as "came back" can also STAY captured.  (With
+    // 8 entries, 9..64 sets cycled in turn were re-captured and evicted on every step -- slower than the eager launches the
+    // detector exists to fall back to)  An instance is seven kernel nodes: a few KB.
+    if (p->cache.size() >= 64) {                     // evict the least recently used instance
         size_t v = 0;
         for (size_t i = 1; i < p->cache.size(); ++i) if (p->cache[i].stamp < p->cache[v].stamp) v = i;
         (void)hipGraphExecDestroy(p->cache[v].exec); (void)hipGraphDestroy(p->cache[v].graph);

@@ -226,9 +226,51 @@ class Dataloader(object):
                 pinned = False
         script = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_worker.py')
         K = self.num_workers
-        procs = [subprocess.Popen([sys.executable, script, path, str(slots), str(H), str(W)], stdin=subprocess.PIPE,
-                                  stdout=subprocess.PIPE, text=True, bufsize=1) for _ in range(K)]
+        import queue
+        import threading
+        procs, answers, path_gone = [], [], False
+
+        def unlink_ring():
+            nonlocal path_gone
+            if not path_gone:
+                path_gone = True
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
         try:
+            procs = [subprocess.Popen([sys.executable, script, path, str(slots), str(H), str(W)], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, text=True, bufsize=1) for _ in range(K)]
+            # One reader thread per worker drains its stdout into a queue: the parent writes the paths of several batches
+            # before it reads an answer, and a worker whose 64 KB stdout pipe is full (long error lines, few workers, big
+            # batches) would otherwise block while the parent blocks on ITS stdin -- a deadlock instead of the RuntimeError.
+            answers = [queue.Queue() for _ in range(K)]
+
+            def drain(w):
+                try:
+                    for line in procs[w].stdout:
+                        answers[w].put(line)
+                finally:
+                    answers[w].put('')                           # EOF marker: the worker is gone
+
+            for w in range(K):
+                threading.Thread(target=drain, args=(w,), daemon=True).start()
+
+            def answer(w, timeout=None):
+                try:
+                    ans = answers[w].get(timeout=timeout)
+                except queue.Empty:
+                    raise RuntimeError('decode worker %d did not answer within %s s' % (w, timeout))
+                if not ans:
+                    raise RuntimeError('decode worker %d exited (code %s)' % (w, procs[w].poll()))
+                return ans.rstrip('\n')
+            # every worker reports once it has mapped the ring; the FILE is then unlinked at once -- the mappings (ours, page-
+            # locked, and the workers') keep the memory alive, and nothing is left under /dev/shm when this process exits,
+            # is interrupted or is killed (a ring is 2 * nbuf * B * H * W * 3 bytes of tmpfs RAM: 147 MB at B=64, 240x320)
+            for w in range(K):
+                if answer(w, timeout=120) != 'ready':
+                    raise RuntimeError('decode worker %d: unexpected greeting' % w)
+            unlink_ring()
             ids_iter = self._id_batches()
             inflight = []                                        # (buffer index, ids, frames handed to each worker)
             free = list(range(nbuf))
@@ -255,11 +297,10 @@ class Dataloader(object):
                 buf, ids, count = inflight.pop(0)
                 for w, n in enumerate(count):                    # every worker answers its lines in order
                     for _ in range(n):
-                        ans = procs[w].stdout.readline()
-                        if not ans:
-                            raise RuntimeError('decode worker %d exited (code %s)' % (w, procs[w].poll()))
-                        if '!' in ans:
-                            raise RuntimeError('decode worker: ' + ans.strip())
+                        ans = answer(w)
+                        body = ans.split(' ', 1)
+                        if len(body) > 1 and body[1].startswith('!'):          # "slot !ErrorType: message"
+                            raise RuntimeError('decode worker: ' + ans)
                 I8 = torch.from_numpy(frames[buf, 0]).to(self.device, non_blocking=pinned)
                 Ip8 = torch.from_numpy(frames[buf, 1]).to(self.device, non_blocking=pinned)
                 if pinned:                                       # the ring slot is free again once the DMA has read it
@@ -284,10 +325,7 @@ class Dataloader(object):
                 except Exception:
                     pass
             del frames
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+            unlink_ring()
 
     def _prefetched(self, gen, depth):
         import queue
@@ -322,8 +360,8 @@ class Dataloader(object):
             finally:
                 gen.close()                                   # stops the decode workers / frees the frame ring, if any
 
-        t = threading.Thread(target=producer, daemon=True)
-        t.start()
+        worker = threading.Thread(target=producer, daemon=True)
+        worker.start()
         try:
             while True:
                 item, ev = q.get()
@@ -332,12 +370,20 @@ class Dataloader(object):
                 if ev is not None:
                     cur = torch.cuda.current_stream(self.device)
                     cur.wait_event(ev)
-                    for t in item.values():                   # allocated on the producer's stream, consumed on this one
-                        if torch.is_tensor(t) and t.is_cuda:
-                            t.record_stream(cur)
+                    for ten in item.values():                 # allocated on the producer's stream, consumed on this one
+                        if torch.is_tensor(ten) and ten.is_cuda:
+                            ten.record_stream(cur)
                 yield item
         finally:
+            # closing (or dropping) this generator must END the producer: it is the producer's `finally` that stops the decode
+            # workers and releases the page-locked frame ring; a daemon thread that is merely abandoned never gets there
             stop.set()
+            try:
+                while True:                                   # a producer blocked on a full queue sees `stop` within 0.1 s;
+                    q.get_nowait()                            # draining lets one blocked on put() of an exception return too
+            except queue.Empty:
+                pass
+            worker.join(timeout=30)
 
     def __iter__(self):
         """One epoch = ceil(n / batch_size) full batches; the last one is completed with the first pairs of the next

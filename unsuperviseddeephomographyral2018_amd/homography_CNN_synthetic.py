@@ -376,49 +376,54 @@ def train(args):
     _lib.dlt_zeroed_pairs(reset=True)
     zeroed_pairs = 0
     t0 = time.time()
-    for step in range(start_step, start_step + args.num_total_steps):
+    try:
+        for step in range(start_step, start_step + args.num_total_steps):
+            if disk is not None:
+                batch = next(disk)
+            elif pool:
+                if not order:
+                    order = torch.randperm(len(pool), generator=pool_gen).tolist()
+                batch = pool[order.pop()]
+            elif batch is None or (step - start_step) % max(args.fresh_data_every, 1) == 0:
+                # every rank draws its own shard (seeded by step and rank) == tf.split of a global batch
+                batch = synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
+                                             seed=args.seed + step * world + rank, device=device, kind=args.texture)
+            model = step_fn(batch)
+            vals = uh_dist.all_reduce_mean_scalars([getattr(model, n) for n in names], world)
+            cur = torch.stack([v.detach() for v in vals])
+            finite = torch.isfinite(cur)
+            nonfinite_steps += (~finite.all()).float()          # a degenerate pair makes that step's loss VALUE NaN (its gradient is
+            cur = torch.where(finite, cur, torch.zeros_like(cur))   # zeroed in the DLT backward): keep it out of the running means
+            totals += cur
+            window += cur
+            win_n += 1
+            if step % args.log_every == 0:                       # every rank: its device's count of zeroed pairs, summed over ranks
+                z = _lib.dlt_zeroed_pairs(reset=True)            # (synchronous read of a device counter: log time only)
+                if world > 1:
+                    zt = torch.tensor([z], dtype=torch.int64, device=device)
+                    torch.distributed.all_reduce(zt)
+                    z = int(zt.item())
+                zeroed_pairs += z
+            if rank == 0 and step % args.log_every == 0:
+                n = step - start_step + 1
+                avg = (totals / n).tolist()                      # running means since the start, as the reference prints (:345-352)
+                win = (window / win_n).tolist()                  # ... and the mean over the steps since the previous log line
+                dt = time.time() - t0
+                print('Train: step %d  ' % step + ', '.join('%s %.6f' % (k, v) for k, v in zip(names, avg))
+                      + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
+                      + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)])
+                      + ('  | %d steps with a non-finite loss value so far' % int(nonfinite_steps) if float(nonfinite_steps) else '')
+                      + ('  | %d pairs had a non-finite gradient zeroed so far (--zero_nonfinite_grad; the reference would have '
+                         'propagated NaN)' % zeroed_pairs if zeroed_pairs else ''),
+                      flush=True)
+                window.zero_(); win_n = 0
+            if rank == 0 and step and step % args.save_every == 0:
+                os.makedirs(ckpt_dir, exist_ok=True)
+                torch.save(step_fn.state_dict(), ckpt)
+    finally:
         if disk is not None:
-            batch = next(disk)
-        elif pool:
-            if not order:
-                order = torch.randperm(len(pool), generator=pool_gen).tolist()
-            batch = pool[order.pop()]
-        elif batch is None or (step - start_step) % max(args.fresh_data_every, 1) == 0:
-            # every rank draws its own shard (seeded by step and rank) == tf.split of a global batch
-            batch = synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
-                                         seed=args.seed + step * world + rank, device=device, kind=args.texture)
-        model = step_fn(batch)
-        vals = uh_dist.all_reduce_mean_scalars([getattr(model, n) for n in names], world)
-        cur = torch.stack([v.detach() for v in vals])
-        finite = torch.isfinite(cur)
-        nonfinite_steps += (~finite.all()).float()          # a degenerate pair makes that step's loss VALUE NaN (its gradient is
-        cur = torch.where(finite, cur, torch.zeros_like(cur))   # zeroed in the DLT backward): keep it out of the running means
-        totals += cur
-        window += cur
-        win_n += 1
-        if step % args.log_every == 0:                       # every rank: its device's count of zeroed pairs, summed over ranks
-            z = _lib.dlt_zeroed_pairs(reset=True)            # (synchronous read of a device counter: log time only)
-            if world > 1:
-                zt = torch.tensor([z], dtype=torch.int64, device=device)
-                torch.distributed.all_reduce(zt)
-                z = int(zt.item())
-            zeroed_pairs += z
-        if rank == 0 and step % args.log_every == 0:
-            n = step - start_step + 1
-            avg = (totals / n).tolist()                      # running means since the start, as the reference prints (:345-352)
-            win = (window / win_n).tolist()                  # ... and the mean over the steps since the previous log line
-            dt = time.time() - t0
-            print('Train: step %d  ' % step + ', '.join('%s %.6f' % (k, v) for k, v in zip(names, avg))
-                  + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
-                  + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)])
-                  + ('  | %d steps with a non-finite loss value so far' % int(nonfinite_steps) if float(nonfinite_steps) else '')
-                  + ('  | %d pairs had a non-finite gradient zeroed so far (--zero_nonfinite_grad; the reference would have '
-                     'propagated NaN)' % zeroed_pairs if zeroed_pairs else ''),
-                  flush=True)
-            window.zero_(); win_n = 0
-        if rank == 0 and step and step % args.save_every == 0:
-            os.makedirs(ckpt_dir, exist_ok=True)
-            torch.save(step_fn.state_dict(), ckpt)
+            disk.close()             # ends the producer thread, the decode workers and the page-locked frame ring -- also on
+                                     # an exception or Ctrl-C (the ring used to outlive the process)
     if rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)
         torch.save(step_fn.state_dict(), ckpt)          # Save the final model (:389)
