@@ -65,6 +65,10 @@ def parse():
                     help='1: add gt + N(0, 2 px) to the regressor output inside the timed steps, so that theta follows SURVEY '
                          '8(d)\'s mid-training law (perspective, clipped and far-field tiles) instead of the near-identity a '
                          '25-step-old regressor predicts; 0: the raw regressor')
+    ap.add_argument('--traffic', type=int, default=1,
+                    help='1 (N = 1 only): measure roofline.traffic IN THIS RUN -- two child runs of this script under `rocprofv3 '
+                         '--pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (separate passes) after the headline; 0: read the committed file')
+    ap.add_argument('--traffic_child', type=int, default=0, help='(internal) this process is one of those child runs')
     ap.add_argument('--quality', type=int, default=1, help='0: skip the mean-corner-error training run')
     ap.add_argument('--quality_steps', type=int, default=8000, help='training steps of the quality run (~5.6 ms each)')
     ap.add_argument('--quality_pool', type=int, default=384, help='in-HBM pool of pre-generated training batches (118 MB each)')
@@ -241,9 +245,24 @@ def warp_point(device, B, H, W, P, rho, iters=30, seed=7, warm=30):
             'timing': 'HIP start/stop events of each dispatch (uh_profile_*), %d launches after %d untimed ones' % (iters, warm)}
 
 
+def library_fingerprint():
+    """sha256 over the kernel sources + build flags the loaded library was built from (build._fingerprint(); the stamp beside
+    the .so when it exists -- the GPU box has no need to re-hash -- else computed)."""
+    from unsuperviseddeephomographyral2018_amd import build as uh_build
+    try:
+        return open(uh_build.LIB + '.sha256').read().strip()
+    except Exception:
+        return uh_build._fingerprint()
+
+
+TRAFFIC_FILES = ('traffic_r04.json', 'traffic_r03.json', 'traffic_r02.json', 'traffic_r01.json')
+
+
 def committed_traffic(key):
-    """HBM bytes per launch from the committed PMC file (profiles/traffic_rNN.json) -- NOT measured in this run."""
-    for name in ('traffic_r03.json', 'traffic_r02.json', 'traffic_r01.json'):
+    """HBM bytes per launch from the newest committed PMC file (profiles/traffic_rNN.json) -- NOT measured in this run.
+    `stale` says whether the file was measured on other kernel sources than the loaded library's (fingerprint stored in the
+    file by tools/gpu_session.sh traffic; files from before round 4 carry none and count as stale)."""
+    for name in TRAFFIC_FILES:
         f = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(f):
             try:
@@ -251,9 +270,91 @@ def committed_traffic(key):
             except Exception:
                 continue
             if key in tr:
+                fp = tr.get('_fingerprint')
                 return {'hbm_bytes_per_launch': tr[key]['hbm_bytes_per_launch'], 'file': 'profiles/' + name,
                         'provenance': tr.get('_provenance', 'no provenance recorded'),
+                        'stale': (fp is None) or (fp != library_fingerprint()),
                         'note': 'read from the committed file, not measured in this run'}
+    return None
+
+
+def measure_traffic(args, timeout_s=300):
+    """roofline.traffic measured IN THIS RUN: this script re-runs itself twice as a child under
+    `rocprofv3 --pmc <counter> --kernel-trace` -- FETCH_SIZE and WRITE_SIZE in their own passes, nothing but --kernel-trace
+    beside --pmc, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- for 5 + 3 steps of the same workload followed by
+    the config-4 point, and reads every warp kernel's counters back.  The two shapes share kernel names; they are told apart
+    by grid size.  HBM bytes per launch = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024 (gfx950 tallies a 128-byte fabric
+    read as 64 B: the guide's correction, re-calibrated in this repo on a device copy of known size, profiles/r01a_pmc_*).
+    -> {(kernel, blocks): bytes} keyed as '<kernel>@<blocks>' plus provenance; {'error': ...} when rocprofv3 is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    tool = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(tool):
+        return {'error': 'rocprofv3 not found'}
+    child = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '3', '--cpu_baseline', '0', '--north_star', '0',
+             '--config4', '1' if args.config4 else '0', '--quality', '0', '--traffic', '0', '--traffic_child', '1', '--profile', '0',
+             '--per_gpu_batch', str(args.per_gpu_batch), '--img_h', str(args.img_h), '--img_w', str(args.img_w),
+             '--patch_size', str(args.patch_size), '--rho', str(args.rho), '--loss_type', args.loss_type,
+             '--fused_patch', str(args.fused_patch), '--mid_training_theta', str(args.mid_training_theta)]
+    vals = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir='/tmp') as td:
+        env = dict(os.environ, TMPDIR='/tmp')
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(td, counter)
+            cmd = [tool, '--pmc', counter, '--kernel-trace', '-d', out, '-o', 'p', '--output-format', 'csv', '--'] + child
+            try:
+                pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                      start_new_session=True)
+                try:
+                    pr.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)        # exactly the process group started here
+                    pr.wait()
+                    return {'error': 'rocprofv3 --pmc %s pass exceeded %d s' % (counter, timeout_s)}
+            except Exception as e:                              # noqa: BLE001
+                return {'error': 'rocprofv3 --pmc %s: %s' % (counter, e)}
+            rows = 0
+            for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
+                for r in csv.DictReader(open(f)):
+                    k = r.get('Kernel_Name', '')
+                    if 'uh::warp_' not in k or r.get('Counter_Name') != counter:
+                        continue
+                    name = k.replace('void ', '').split('(')[0].replace('uh::', '')
+                    wg = int(float(r.get('Workgroup_Size', 256) or 256))
+                    blocks = int(float(r.get('Grid_Size', 0) or 0)) // max(wg, 1)
+                    vals.setdefault((name, blocks), {}).setdefault(counter, []).append(float(r['Counter_Value']))
+                    rows += 1
+            if rows == 0:
+                return {'error': 'rocprofv3 --pmc %s pass produced no warp-kernel rows (rc %s)' % (counter, pr.returncode)}
+    res = {'_seconds': round(time.perf_counter() - t0, 1),
+           '_how': 'measured in this run: 2 child runs of bench.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes, '
+                   '--kernel-trace only); bytes = median FETCH_SIZE KiB x 1024 x 2 + median WRITE_SIZE KiB x 1024 per launch '
+                   '(gfx950 correction of the microarchitecture guide, calibrated on a device copy)',
+           '_fingerprint': library_fingerprint()}
+    for (name, blocks), cs in vals.items():
+        if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
+            med = lambda v: sorted(v)[len(v) // 2]
+            res['%s@%d' % (name, blocks)] = {'hbm_bytes_per_launch': int(med(cs['FETCH_SIZE']) * 2048 + med(cs['WRITE_SIZE']) * 1024),
+                                             'FETCH_SIZE_KiB_median': med(cs['FETCH_SIZE']), 'WRITE_SIZE_KiB_median': med(cs['WRITE_SIZE']),
+                                             'launches_seen': len(cs['FETCH_SIZE'])}
+    return res
+
+
+def traffic_lookup(measured, family, blocks):
+    """bytes per launch of the `family` kernel ('warp_forward_kernel' / 'warp_backward_kernel', dense instantiation) launched
+    with `blocks` workgroups, from measure_traffic()'s result; None if absent."""
+    if not measured or 'error' in measured:
+        return None
+    for k, v in measured.items():
+        if k.startswith(family + '<') and k.endswith('@%d' % blocks) and isinstance(v, dict):
+            if family == 'warp_backward_kernel' and not k.split('@')[0].endswith(', false>'):
+                continue                                       # PATCH-mode instantiation: the sparse backward of the step
+            return v
     return None
 
 
@@ -266,7 +367,7 @@ def config4_point(device, args):
     """BASELINE.json configs[3]: full-frame 480x640 warp, rho = 64, batch 128 -- 1.9 GB working set, far beyond the
     256 MB Infinity Cache: the HBM-resident roofline point."""
     r = warp_point(device, 128, 480, 640, args.patch_size, 64, iters=30, warm=30)
-    r['traffic_fwd'] = committed_traffic('warp_forward_B128_480x640')
+    r['traffic_fwd'] = committed_traffic('warp_forward_B128_480x640')      # replaced by this run's own PMC passes in main()
     r['traffic_bwd'] = committed_traffic('warp_backward_B128_480x640')
     return r
 
@@ -424,21 +525,15 @@ def main():
                     'algorithmic_bytes_per_launch': alg, 'avg_launch_us': kern[dom]['avg_us'],
                     'timing': 'HIP start/stop events of each dispatch on its launch stream (hipExtLaunchKernelGGL via '
                               'uh_profile_*), inside the timed region', 'kernels': kern}
-    # HBM bytes per launch of the dominant kernel from the PMC passes over THIS command (tools/gpu_traffic.sh ->
-    # profiles/traffic_r01.json; FETCH_SIZE x2 KiB + WRITE_SIZE KiB, the gfx950 correction calibrated on a device copy)
-    traffic_file = next((f for f in (os.path.join(ROOT, 'profiles', n) for n in ('traffic_r03.json', 'traffic_r02.json',
-                                                                               'traffic_r01.json')) if os.path.exists(f)), '')
-    if dom is not None and os.path.exists(traffic_file):
-        try:
-            tr = json.load(open(traffic_file))
-            key = '%s_B%d_%dx%d' % (dom, B, args.img_h, args.img_w)
-            if key in tr:
-                roofline['traffic'] = tr[key]['hbm_bytes_per_launch']
-                roofline['traffic_source'] = tr[key].get('source', os.path.basename(traffic_file))
-                roofline['traffic_note'] = ('NOT measured in this run: read from the committed file %s (%s)'
-                                            % (os.path.relpath(traffic_file, ROOT), tr.get('_provenance', 'no provenance recorded')))
-        except Exception:
-            pass
+    # HBM bytes per launch of the dominant kernel: from the committed PMC file first (flagged when it was measured on other
+    # kernel sources than the loaded library's); replaced further down by THIS run's own PMC passes (--traffic 1, N = 1)
+    if dom is not None:
+        ct = committed_traffic('%s_B%d_%dx%d' % (dom, B, args.img_h, args.img_w))
+        if ct is not None:
+            roofline['traffic'] = ct['hbm_bytes_per_launch']
+            roofline['traffic_stale'] = ct['stale']
+            roofline['traffic_note'] = 'NOT measured in this run: read from the committed file %s (%s)%s' % (
+                ct['file'], ct['provenance'], '; STALE: measured on other kernel sources than the loaded library' if ct['stale'] else '')
     out = {
         'metric': 'image-pairs/sec (train step) + mean corner error, 128x128 patch RHO=45', 'value': round(value, 1),
         'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -484,12 +579,31 @@ def main():
         out['north_star_point'] = guarded(north_star_point, device, args)
     if world == 1 and args.config4:
         out['config4_point'] = guarded(config4_point, device, args)
+    if world == 1 and args.traffic and not args.traffic_child and dom is not None:
+        mt = guarded(measure_traffic, args)
+        out['roofline']['traffic_measurement'] = {k: v for k, v in mt.items() if k.startswith('_') or k == 'error'}
+        blocks_of = lambda nb, hh, ww: nb * ((ww + 63) // 64) * ((hh + 15) // 16)
+        if dom == 'warp_forward':
+            hit = traffic_lookup(mt, 'warp_forward_kernel', blocks_of(B, args.img_h, args.img_w))
+            if hit is not None:
+                out['roofline']['traffic'] = hit['hbm_bytes_per_launch']
+                out['roofline']['traffic_stale'] = False
+                out['roofline']['traffic_note'] = mt['_how'] + '; %d launches of the in-step shape seen' % hit['launches_seen']
+                out['roofline']['traffic_over_algorithmic'] = round(hit['hbm_bytes_per_launch'] / alg, 4)
+        if isinstance(out.get('config4_point'), dict) and 'error' not in out['config4_point']:
+            for side, fam in (('traffic_fwd', 'warp_forward_kernel'), ('traffic_bwd', 'warp_backward_kernel')):
+                hit = traffic_lookup(mt, fam, blocks_of(128, 480, 640))
+                if hit is not None:
+                    out['config4_point'][side] = {'hbm_bytes_per_launch': hit['hbm_bytes_per_launch'], 'stale': False,
+                                                  'launches_seen': hit['launches_seen'], 'note': 'measured in this run (PMC child passes)'}
     if world == 1 and args.cpu_baseline:
         out['cpu_baseline'] = guarded(cpu_baseline, args, batch, step_fn.h4p_offset)
     if world == 1 and args.quality and args.loss_type == 'l1_loss':
         del step_fn, model
         torch.cuda.empty_cache()
         out['quality'] = guarded(quality_run, device, args)
+    out['timing_note'] = ('per-dispatch HIP events on the warp kernels inside the timed region (--profile 1) cost a small pipeline '
+                          'bubble each: the headline is understated by ~0.5 %% (measured with --profile 0)') if args.profile else None
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -79,6 +79,19 @@ for ST in "$@"; do
             done ;;
     cold)   timeout 600 python tools/cold_forward.py --tag $TAG > gpurun_out/${TAG}_cold_forward.jsonl 2> gpurun_out/${TAG}_cold_forward.err; cat gpurun_out/${TAG}_cold_forward.jsonl | cut -c1-260; tail -3 gpurun_out/${TAG}_cold_forward.err ;;
     train_ref) TAG=$TAG bash tools/train_reference_schedule.sh ;;
+    dpnoise) UH_TEST_NONDET=1 timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line > gpurun_out/${TAG}_pytest_dp_product_default_solvers.log 2>&1; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_product_default_solvers.log | cut -c1-900 ;;
+    power)  timeout 900 python tools/power_ab.py --libs ${A1:-shipped} --kernel ${A2:-bwd} --seconds 4 --reps 2 > gpurun_out/${TAG}_power_${A2:-bwd}.jsonl 2> gpurun_out/${TAG}_power.err; cat gpurun_out/${TAG}_power_${A2:-bwd}.jsonl ;;
+    coldv)  : > gpurun_out/${TAG}_cold_forward_variants.jsonl
+            for rep in 1 2; do
+              timeout 300 python tools/cold_forward.py --tag shipped --batches 64,128 2>/dev/null | grep -v fit >> gpurun_out/${TAG}_cold_forward_variants.jsonl
+              for V in ${A1//,/ }; do UH_LIB_PATH=$VDIR/libuh_$V.so timeout 300 python tools/cold_forward.py --tag $V --batches 64,128 2>/dev/null | grep -v fit >> gpurun_out/${TAG}_cold_forward_variants.jsonl; done
+            done
+            python - <<PYEOF
+import json
+for l in open('gpurun_out/${TAG}_cold_forward_variants.jsonl'):
+    d = json.loads(l); print(d['tag'], d['B'], d['law'], d['temp'], d['us'], d['frac'])
+PYEOF
+            ;;
     *) echo "unknown stage $NAME" ;;
   esac
 done

@@ -43,7 +43,22 @@ def init_from_env(backend=None):
             backend = os.environ.get('UH_DIST_BACKEND') or ('nccl' if enough else 'gloo')
         if torch.cuda.is_available():                                      # "nccl" IS RCCL on ROCm
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == 'gloo':
+            # gloo's C++ side prints "[Gloo] Rank r is connected to n peer ranks" on STDOUT when the group forms: a launcher
+            # contract that reads ONE JSON line from stdout (bench.py) must not see it -> fd 1 points at stderr meanwhile
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+                if dist.is_initialized():
+                    dist.barrier()                               # the pairwise connections (and their message) happen here
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
