@@ -245,6 +245,46 @@ def warp_point(device, B, H, W, P, rho, iters=30, seed=7, warm=30):
             'timing': 'HIP start/stop events of each dispatch (uh_profile_*), %d launches after %d untimed ones' % (iters, warm)}
 
 
+def forward_temperatures(device, U, theta, H, W, iters=30, evict_mb=1024):
+    """The in-step forward launch replayed outside the step on the step's own `U` and theta: `warm` =
+    back-to-back launches (the input is served by the 256 MB Infinity Cache / L2), `cold` = a 1 GiB device copy before every
+    launch, i.e. the state the train step leaves the caches in (a whole conv stack runs between two warp launches).
+    Durations are dispatch start/stop events (uh_profile_*), like the in-step reading.  tools/cold_forward.py sweeps the batch
+    size around this point: t(B) is a straight line (residuals <= 0.4 us) -- no round-of-blocks quantisation -- with a fixed
+    cost of 9.5 us cold / 7 us warm and an asymptotic streaming rate of 0.78 x 8 TB/s cold (the float4-copy yardstick)."""
+    import ctypes as C
+    from unsuperviseddeephomographyral2018_amd import _lib
+    lib = _lib.load()
+    B = U.shape[0]
+    out = torch.empty_like(U)
+    theta = theta.detach().contiguous()
+    ev_a = torch.empty(evict_mb * (1 << 20) // 4, device=device).normal_()
+    ev_b = torch.empty_like(ev_a)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    res = {}
+    for temp in ('warm', 'cold'):
+        def fwd():
+            _lib.check(lib.uh_warp_forward(p(U), p(theta), p(out), None, B, H, W, 3, H, W,
+                                           C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), 'uh_warp_forward')
+        for _ in range(10):
+            fwd()
+        torch.cuda.synchronize(device)
+        _lib.profile_enable(True, only=('warp_forward',))
+        for _ in range(iters):
+            if temp == 'cold':
+                ev_b.copy_(ev_a)
+            fwd()
+        torch.cuda.synchronize(device)
+        pr = _lib.profile_read()
+        _lib.profile_enable(False)
+        us = pr['warp_forward'][0] / max(pr['warp_forward'][1], 1) * 1e3
+        res[temp + '_us'] = round(us, 2)
+        res[temp + '_frac'] = round(2 * B * H * W * 3 * 4 / (us * 1e-6) / HBM_PEAK, 4)
+    del ev_a, ev_b, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def library_fingerprint():
     """sha256 over the kernel sources + build flags the loaded library was built from (build._fingerprint(); the stamp beside
     the .so when it exists -- the GPU box has no need to re-hash -- else computed)."""
@@ -401,6 +441,7 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = True                   # MIOpen find: pick the fastest f32 conv solvers
+    uh_dist.skip_naive_conv_in_find()                       # ... without benchmarking MIOpen's reference (naive) solvers
     torch.manual_seed(1234)
 
     if args.only_points:
@@ -432,9 +473,11 @@ def main():
         g = torch.Generator(device=device).manual_seed(4321 + rank)
         step_fn.h4p_offset = batch['gt'] + 2.0 * torch.randn(B, 8, generator=g, device=device)
     find_pass_s = step_fn.prime_conv_finds(batch)           # world > 1: MIOpen find by rank 0 first (untimed, before the warm-up)
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         model = step_fn(batch)
     torch.cuda.synchronize(device)
+    warmup_s = time.perf_counter() - t_w                    # MIOpen find (kernel builds + trials) lives here at N = 1
     if world > 1:
         torch.distributed.barrier()
     # profile 1 (default): time only the kernels the roofline object reports -- every timed dispatch costs a small
@@ -481,6 +524,12 @@ def main():
                          'warp_forward_avg_us': round(us2, 2),
                          'frac': round(2 * B * args.img_h * args.img_w * 3 * 4 / (us2 * 1e-6) / HBM_PEAK, 4),
                          'tile_paths': tile_paths(th2, args.img_h, args.img_w)}
+    temps = None
+    if args.profile and world == 1 and not args.step_graph and not args.fused_patch and not args.traffic_child:
+        try:
+            temps = forward_temperatures(device, batch['I_aug'], th_last, args.img_h, args.img_w)
+        except Exception as e:                              # noqa: BLE001 -- an extra, must not lose the headline
+            temps = {'error': '%s: %s' % (type(e).__name__, e)}
     loss_val = float(model.loss.detach())
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -551,8 +600,21 @@ def main():
         'roofline': roofline,
     }
     out['config']['in_step_theta'] = in_step_theta
+    out['config']['warmup_seconds'] = round(warmup_s, 1)
+    out['config']['miopen_find'] = ('cudnn.benchmark = True; reference solvers excluded from the trials '
+                                    '(MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD/BWD/WRW=%s)' % os.environ.get('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'))
     if other_law is not None and isinstance(out.get('roofline'), dict):
         out['roofline']['same_kernel_under_round1_law'] = other_law
+    if temps is not None and dom == 'warp_forward':
+        t_in = out['roofline']['avg_launch_us']
+        temps['in_step_us'] = t_in
+        if 'error' not in temps:
+            temps['reading'] = ('the in-step launch costs what the same launch costs after a 1 GiB evicting copy (cold), %.1f us more '
+                                'than back to back (warm): the gap between roofline.frac and the warm figure is COLD INPUT, not grid '
+                                'tail -- t(B) over B = 32..128 is a straight line (profiles/r04_cold_forward.jsonl: residuals <= 0.4 us; '
+                                'fixed 9.5 us + 0.295 us/pair cold = 0.78 x 8 TB/s asymptotically, the float4-copy yardstick)'
+                                % (temps['cold_us'] - temps['warm_us']))
+        out['roofline']['why_in_step_frac_is_below_the_warm_point'] = temps
     if world > 1:
         out['config']['world_size'] = torch.distributed.get_world_size()
         out['config']['dist_backend'] = torch.distributed.get_backend()

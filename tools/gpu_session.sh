@@ -25,7 +25,7 @@ TAG=$1; shift
 COMMIT=${UH_COMMIT:-unknown}
 VDIR=unsuperviseddeephomographyral2018_amd/lib/variants
 MCFG=${MCFG:-"128,240,320,128,45;128,480,640,128,64"}
-BENCH="python /root/repo/bench.py --steps 30 --warmup 5 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0"
+BENCH="python /root/repo/bench.py --steps 30 --warmup 5 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --traffic 0"
 for ST in "$@"; do
   IFS=: read -r NAME A1 A2 <<< "$ST"
   echo "== stage $NAME $A1 $A2"
@@ -42,16 +42,18 @@ for ST in "$@"; do
     rocprof)
             ( cd /tmp && rm -rf /tmp/prof_$TAG && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench --output-format csv -- $BENCH > /root/repo/gpurun_out/${TAG}_bench_line_under_rocprof.json 2>/dev/null )
             cp $(find /tmp/prof_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_bench_kernel_stats.csv 2>/dev/null
-            python tools/step_breakdown.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 20 60 > gpurun_out/${TAG}_step_breakdown.txt 2>&1 ;;
+            python tools/step_breakdown.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 20 60 > gpurun_out/${TAG}_step_breakdown.txt 2>&1
+            python tools/timed_steps_stats.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 5 30 > gpurun_out/${TAG}_bench_kernel_stats_timed_steps.csv 2> gpurun_out/${TAG}_timed_steps.err
+            grep -E "warp_|Block" gpurun_out/${TAG}_bench_kernel_stats_timed_steps.csv | cut -c1-260 ;;
     rocprof_c4)
             ( cd /tmp && rm -rf /tmp/prof4_$TAG && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof4_$TAG -o c4 --output-format csv -- python /root/repo/bench.py --only_points config4 > /root/repo/gpurun_out/${TAG}_config4_point_under_rocprof.json 2>/dev/null )
             cp $(find /tmp/prof4_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_config4_kernel_stats.csv 2>/dev/null
             grep -E "warp_(forward|backward)_kernel" gpurun_out/${TAG}_config4_kernel_stats.csv | cut -c1-200 ;;
     traffic)
             for W in bench c4; do
-              if [ $W = bench ]; then PC="python /root/repo/bench.py --steps 5 --warmup 3 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0"; DIMS="64 240 320"; else PC="python /root/repo/bench.py --only_points config4"; DIMS="128 480 640"; fi
+              if [ $W = bench ]; then PC="python /root/repo/bench.py --steps 5 --warmup 3 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --traffic 0 --profile 0"; DIMS="64 240 320"; else PC="python /root/repo/bench.py --only_points config4"; DIMS="128 480 640"; fi
               ( cd /tmp && rm -rf /tmp/pmc_$W && mkdir -p /tmp/pmc_$W && i=0 && for C in "FETCH_SIZE" "WRITE_SIZE"; do i=$((i+1)); timeout 400 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$W/p$i -o p --output-format csv -- $PC > /tmp/pmc_$W/log$i.txt 2>&1 || echo "pmc pass $W $i failed"; done )
-              python tools/traffic_from_pmc.py /tmp/pmc_$W $DIMS gpurun_out/traffic_${TAG}.json "$PC" "measured $(date -u +%Y-%m-%d) on one MI355X at commit $COMMIT by tools/gpu_session.sh traffic" > /dev/null
+              python tools/traffic_from_pmc.py /tmp/pmc_$W $DIMS gpurun_out/traffic_${TAG}.json "$PC" "measured $(date -u +%Y-%m-%d) on one MI355X at commit $COMMIT by tools/gpu_session.sh traffic" "$(cat unsuperviseddeephomographyral2018_amd/lib/libuh_hotpath.so.sha256)" > /dev/null
             done ;;
     pmc_c4) bash tools/gpu_pmc2.sh 128,480,640,128,64 ${TAG}_c4 > gpurun_out/${TAG}_pmc.log 2>&1 ;;
     micro)  : > gpurun_out/${TAG}_micro.jsonl

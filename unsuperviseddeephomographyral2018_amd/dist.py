@@ -62,6 +62,16 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def skip_naive_conv_in_find():
+    """MIOpen's find mode (torch.backends.cudnn.benchmark) also BENCHMARKS its reference solvers -- naive_conv_*: one thread per
+    output, 0.3 s per launch for this network's weight gradients; 48 + 48 + 40 launches = 16.7 of the ~40 s the first step of a
+    rank costs (profiles/r03_bench_kernel_stats.csv) -- which never win.  The documented MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_*
+    switches take them out of the candidate list; MIOpen reads them when it first looks for solvers, so this must run before
+    the first convolution of the process.  An explicit setting in the environment wins."""
+    for k in ('FWD', 'BWD', 'WRW'):
+        os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_' + k, '0')
+
+
 def seed_tower_rng(seed, rank):
     """Every tower draws its OWN dropout masks: the reference builds one slim.dropout op per tower
     (homography_model.py:120-121,128, one model per tower at homography_CNN_synthetic.py:229-233), so the masks of two

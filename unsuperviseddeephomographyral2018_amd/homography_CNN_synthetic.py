@@ -332,6 +332,7 @@ def train(args):
         raise RuntimeError('training needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = True                   # MIOpen find: shapes are static
+    uh_dist.skip_naive_conv_in_find()
     torch.manual_seed(args.seed)
     step_fn = TrainStep(args, device, world)
     ckpt_dir, ckpt = _ckpt_path(args)
