@@ -8,6 +8,7 @@ blocks = 3.1 rounds -- and (iii) the FIXED cost of a launch (ramp-up, drain), by
 
     * warm  : back-to-back launches on the same tensors (what tools/microbench.py and the north-star point measure),
     * cold  : an evicting device copy (>= 1 GiB, four times the Infinity Cache) between launches,
+    * cold+readU (+fill_out): the same, then `U` read once (and `out` written once) before the launch,
     * for B in a sweep that crosses 2.3 / 3.1 / 3.8 / 4.7 / 6.25 rounds of 1 536 resident blocks,
     * under both theta laws: `hard` = DLT(gt + N(0, 2 px)) (SURVEY 8d mid-training law: clipped / far-field tiles) and
       `easy` = DLT(N(0, 1 px)) (what a 25-step-old regressor predicts: every tile interior and staged).
@@ -48,6 +49,7 @@ def main():
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
     resident = 256 * 6
+    sink = torch.zeros((), device=dev)
     fits = {}
     for B in [int(v) for v in args.batches.split(',')]:
         b = synthetic.make_batch(B, H, W, P, args.rho, seed=100, device=dev)
@@ -63,14 +65,21 @@ def main():
 
             def fwd():
                 _lib.check(lib.uh_warp_forward(p(U), p(theta), p(out), None, B, H, W, 3, H, W, st()), 'uh_warp_forward')
-            for temp in ('warm', 'cold'):
+            # cold+readU: after the evicting copy, U is read once (a reduction) before the launch -- what a side-stream prefetch
+            # issued under the fc layers would leave behind; cold+readU+fill_out additionally writes `out` once: together they
+            # say how much of the cold penalty is U coming from HBM, how much the output lines / address translation
+            for temp in ('warm', 'cold', 'cold+readU', 'cold+readU+fill_out'):
                 for _ in range(10):
                     fwd()
                 torch.cuda.synchronize()
                 _lib.profile_enable(True, only=('warp_forward',))
                 for _ in range(args.iters):
-                    if temp == 'cold':
+                    if temp != 'warm':
                         ev_b.copy_(ev_a)                 # 2 x evict_mb of traffic: L2 and Infinity Cache now hold the copy's lines
+                    if temp.startswith('cold+readU'):
+                        torch.sum(U, out=sink)
+                    if temp.endswith('fill_out'):
+                        out.fill_(0.5)
                     fwd()
                 torch.cuda.synchronize()
                 prof = _lib.profile_read()

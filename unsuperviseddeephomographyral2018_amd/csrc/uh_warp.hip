@@ -91,10 +91,6 @@ static_assert(UH_WARP_STEPS % UH_WARP_FWD_BATCH == 0, "batch must divide the ste
                                   // scratch round trip per tile in a kernel that is short of memory slots, not of waves
 #endif
 static_assert(UH_WARP_STEPS_BWD % UH_WARP_BWD_BATCH == 0, "batch must divide the steps");
-#ifndef UH_WARP_BWD_STAGE_G
-#define UH_WARP_BWD_STAGE_G 0     // 1 (developer A/B switch, round 4): the dense backward pulls its 16 x 16 dOut tile into LDS with
-                                  // C buffer_load_dwordx4 ... lds instead of 4 buffer_load_dwordx3 per lane, and reads G at use
-#endif
 constexpr int NWAVE = 4;                // waves per block, side by side in x: block tile = (4*TW) x TH
 constexpr bool STAGE_FWD = UH_WARP_STAGE_FWD != 0, STAGE_BWD = UH_WARP_STAGE_BWD != 0;
 static_assert(TW * WY == 64, "UH_WARP_TW must divide 64");
@@ -614,10 +610,6 @@ __global__ __launch_bounds__(256, (WANT_DU ? 3 : (C == 4 ? UH_WARP_BWD_MINW - 1 
     constexpr int LDSW = UH_WARP_LDS_PER_WAVE_BWD;
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[STAGE_BWD ? NWAVE * LDSW : 16];
     __shared__ float red[9][NWAVE * 4];
-    // dOut tile of the wave, pixel (row r, column c) of the tile at byte (r*TW + c)*C*4: lane l's k-th pixel is at (l + 64 k)*C*4
-    constexpr bool STAGE_G = (UH_WARP_BWD_STAGE_G != 0) && !PATCH;
-    constexpr int GBYTES = TW * TH_B * C * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_gall[STAGE_G ? NWAVE * GBYTES : 16];
     const int lane = threadIdx.x & 63, wave = wave_id();
     unsigned v = xcd_remap(blockIdx.x, nblk);
     int b, ty, tx;
@@ -672,45 +664,8 @@ __global__ __launch_bounds__(256, (WANT_DU ? 3 : (C == 4 ? UH_WARP_BWD_MINW - 1 
         const float rowf0 = (float)row0;                                 // (float)(row0 + k*WY) == rowf0 + k*WY exactly
         Proj p[STEPS_B];
         float fx[STEPS_B], fy[STEPS_B];
-        Pix<C> G[STAGE_G ? 1 : STEPS_B];
+        Pix<C> G[STEPS_B];
         float gy[STEPS_B];
-        unsigned char* ldsg = lds_gall + (STAGE_G ? wave * GBYTES : 0);
-        const unsigned gofs = (unsigned)lane * (C * 4);
-        if constexpr (STAGE_G) {
-            const int wx0 = (tx * NWAVE + wave) * TW;
-            if (wx0 + TW <= ow) {                                        // wave-uniform: the tile's rows are whole 16-pixel runs
-                // chunk q = 64 n + lane of the tile's TH_B x (TW*C*4/16) sixteen-byte chunks; rows >= oh are out of range -> 0
-                constexpr int CPR = TW * C * 4 / 16;
-#pragma unroll
-                for (int n = 0; n < C; ++n) {
-                    const int q = n * 64 + lane;
-                    const int r = q / CPR;                                // (constant divisor)
-                    const int c16 = q - r * CPR;
-                    const unsigned goff = (unsigned)(ty * TH_B + r) * orow + (unsigned)(wx0 * C * 4 + c16 * 16);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(ldsg + n * 1024), 16,
-                                                             goff, 0, 0, 0);
-                }
-            } else {                                                     // right-edge tile: per-pixel loads (range-checked), parked in LDS
-                unsigned vo = col_ok ? (unsigned)row0 * orow + (unsigned)col * (C * 4) : 0x80000000u;
-#pragma unroll
-                for (int k = 0; k < STEPS_B; ++k) {
-                    const Pix<C> gk = buf_load<C, UH_WARP_GLOAD_AUX>(rg, vo, 0);
-                    float* q = reinterpret_cast<float*>(ldsg + gofs + (unsigned)k * (64 * C * 4));
-#pragma unroll
-                    for (int ch = 0; ch < C; ++ch) q[ch] = gk.v[ch];
-                    vo += (unsigned)WY * orow;
-                }
-            }
-        }
-        bool g_landed = false;
-        auto Gat = [&](int k) -> Pix<C> {                               // the lane's k-th dOut pixel
-            if constexpr (STAGE_G) {
-                if (!g_landed) { stage_wait(); g_landed = true; }       // (compile-time straight-line: first use only)
-                return lds_load<C>(ldsg, gofs + (unsigned)k * (64 * C * 4));
-            } else {
-                return G[k];
-            }
-        };
         // lanes past the right/bottom edge read dOut out of range (rows >= oh: offset >= num_records; columns
         // >= ow: offset 2^31) -> the buffer unit returns 0 -> they add exactly 0 to dTheta
         unsigned voff = col_ok ? (unsigned)row0 * orow + (unsigned)col * (C * 4) : 0x80000000u;
@@ -728,7 +683,7 @@ __global__ __launch_bounds__(256, (WANT_DU ? 3 : (C == 4 ? UH_WARP_BWD_MINW - 1 
                 }
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) G[k].v[ch] = gv;
-            } else if constexpr (!STAGE_G) {
+            } else {
                 G[k] = buf_load<C, UH_WARP_GLOAD_AUX>(rg, voff, 0);
             }
             voff += (unsigned)WY * orow;
@@ -749,14 +704,13 @@ __global__ __launch_bounds__(256, (WANT_DU ? 3 : (C == 4 ? UH_WARP_BWD_MINW - 1 
             // (Ic-Ia) - (Id-Ib) == (Ib-Ia) - (Id-Ic) =: u (the mixed second difference), so with the channel sums
             // S1 = sum g u, Sb = sum g (Id-Ib), Sc = sum g (Id-Ic):   dx = ay1 S1 + hy Sb,   dy = ax1 S1 + hx Sc
             float s1 = 0.f, sb = 0.f, sc = 0.f;
-            const Pix<C> Gk = Gat(k);
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
                 const float ddb = Id.v[ch] - Ib.v[ch], ddc = Id.v[ch] - Ic.v[ch];
                 const float u = (Ic.v[ch] - Ia.v[ch]) - ddb;
-                s1 = fmaf(Gk.v[ch], u, s1);
-                sb = fmaf(Gk.v[ch], ddb, sb);
-                sc = fmaf(Gk.v[ch], ddc, sc);
+                s1 = fmaf(G[k].v[ch], u, s1);
+                sb = fmaf(G[k].v[ch], ddb, sb);
+                sc = fmaf(G[k].v[ch], ddc, sc);
             }
             const float dx = fmaf(ay1, s1, hy * sb), dy = fmaf(ax1, s1, hx * sc);
             const float rt = p[k].rt;
@@ -774,13 +728,12 @@ __global__ __launch_bounds__(256, (WANT_DU ? 3 : (C == 4 ? UH_WARP_BWD_MINW - 1 
         auto scatter = [&](int k, const TapOff& o, float ax1, float ax0, float ay1, float ay0, bool live) {
             if (!live) return;
             const float wa = ax1 * ay1, wb = ax1 * ay0, wc = ax0 * ay1, wd = ax0 * ay0;
-            const Pix<C> Gk = Gat(k);
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {          // G is 0 for masked lanes/rows: adds 0
-                atomicAdd(dUb + o.oa / 4 + ch, wa * Gk.v[ch]);
-                atomicAdd(dUb + o.ob / 4 + ch, wb * Gk.v[ch]);
-                atomicAdd(dUb + o.oc / 4 + ch, wc * Gk.v[ch]);
-                atomicAdd(dUb + o.od / 4 + ch, wd * Gk.v[ch]);
+                atomicAdd(dUb + o.oa / 4 + ch, wa * G[k].v[ch]);
+                atomicAdd(dUb + o.ob / 4 + ch, wb * G[k].v[ch]);
+                atomicAdd(dUb + o.oc / 4 + ch, wc * G[k].v[ch]);
+                atomicAdd(dUb + o.od / 4 + ch, wd * G[k].v[ch]);
             }
         };
         if (e.interior) {                                               // wave-uniform
