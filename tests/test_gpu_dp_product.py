@@ -213,3 +213,84 @@ def test_product_dp_towers_draw_different_dropout_masks_and_stay_in_step():
     assert out[0]['masks_differ'] and out[1]['masks_differ']
     for keep in out[0]['mask_keep']:
         assert 0.45 < keep < 0.55
+
+
+def _rccl_worker(q, port):
+    """ONE rank, backend "nccl" (= RCCL): the collectives are identities, the CODE PATH is the multi-GPU one."""
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', LOCAL_WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import copy
+    import torch.distributed as dist
+    from unsuperviseddeephomographyral2018_amd import _lib, dist as D, synthetic
+    from unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic import TrainStep
+    from unsuperviseddeephomographyral2018_amd.homography_model import VGGRegressor
+    _lib.load()
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    out = {'backend': dist.get_backend()}
+    try:
+        out['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                                  # noqa: BLE001
+        out['rccl_version'] = 'unknown (%s)' % e
+    # the averaging collective itself
+    t = torch.arange(8, dtype=torch.float32, device=dev)
+    h = dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True); h.wait()
+    torch.cuda.synchronize(dev)
+    out['avg_identity'] = bool(torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32)))
+    # the product step with the data-parallel machinery ON (world = 2 as far as TrainStep is concerned: variable broadcast,
+    # per-tower seed, staggered find pass with its barriers, flat buckets, hooks issuing async AVG all-reduces on RCCL's
+    # stream, finish() waiting on them before fused Adam) against the plain one-tower step
+    Bt = 4
+    torch.manual_seed(21)
+    net = VGGRegressor(P, dropout_p=0.0)
+    dp = TrainStep(_args('l1_loss', 2 * Bt), dev, 2, net=net)          # per-tower batch = 2*Bt / 2
+    out['avg_in_collective'] = dp.averager._avg_in_collective
+    init = copy.deepcopy(dp.net.state_dict())
+    batch = synthetic.make_batch(Bt, H, W, P, RHO, seed=9, device=dev, kind='white')
+    out['t_find'] = dp.prime_conv_finds(batch)
+    for _ in range(STEPS):
+        dp(batch)
+    torch.cuda.synchronize(dev)
+    var_dp = [p.detach().clone() for p in dp.net.parameters()]
+    net1 = VGGRegressor(P, dropout_p=0.0)
+    one = TrainStep(_args('l1_loss', Bt), dev, 1, net=net1)
+    one.net.load_state_dict(init)
+    for _ in range(STEPS):
+        one(batch)
+    torch.cuda.synchronize(dev)
+    var_one = [p.detach().clone() for p in one.net.parameters()]
+    out['var_diff'] = _diff(var_dp, var_one)
+    out['moved'] = _diff(var_dp, [init[n] for n, _ in dp.net.named_parameters()])[0]
+    out['buckets_ms'] = [b['ms'] for b in dp.averager.time_buckets(iters=3)]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(out)
+
+
+def test_product_step_over_rccl_one_rank_equals_plain_step():
+    """The RCCL leg of the data-parallel step has never met hardware with more than one GPU (every box of the pool has one).
+    What CAN run here: a one-rank "nccl" group, where every collective is an identity -- so TrainStep with its data-parallel
+    machinery switched on (broadcast, barriers of the staggered find pass, bucket hooks issuing asynchronous
+    ReduceOp.AVG all-reduces on RCCL's own stream, finish() ordering them before fused Adam) must reproduce the plain step
+    bit for bit.  Catches an RCCL build without AVG, a missing stream dependency between the collective and Adam, a
+    barrier that needs a device it was not given."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q, _free_port()))
+    p.start()
+    try:
+        out = q.get(timeout=600)
+    finally:
+        p.join(timeout=120)
+        if p.is_alive():
+            p.kill()
+    print('one-rank RCCL step:', out)
+    assert p.exitcode == 0
+    assert out['backend'] == 'nccl' and out['avg_identity'] and out['avg_in_collective']
+    assert out['moved'] > 1e-4
+    assert out['var_diff'][1] <= 1e-7 and out['var_diff'][0] <= 1e-5, out['var_diff']     # measured: (0.0, 0.0)
