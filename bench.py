@@ -318,7 +318,7 @@ def committed_traffic(key):
     return None
 
 
-def measure_traffic(args, timeout_s=300):
+def measure_traffic(args, timeout_s=180):
     """roofline.traffic measured IN THIS RUN: this script re-runs itself twice as a child under
     `rocprofv3 --pmc <counter> --kernel-trace` -- FETCH_SIZE and WRITE_SIZE in their own passes, nothing but --kernel-trace
     beside --pmc, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- for 5 + 3 steps of the same workload followed by
@@ -440,7 +440,9 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = True                   # MIOpen find: pick the fastest f32 conv solvers
+    # MIOpen find: pick the fastest f32 conv solvers.  (The PMC child runs of measure_traffic() only need the warp kernels'
+    # counters: immediate mode there, so that no find-mode trial kernel is profiled.)
+    torch.backends.cudnn.benchmark = not args.traffic_child
     uh_dist.skip_naive_conv_in_find()                       # ... without benchmarking MIOpen's reference (naive) solvers
     torch.manual_seed(1234)
 
