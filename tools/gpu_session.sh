@@ -79,8 +79,9 @@ for ST in "$@"; do
               echo "rc $? stagger $SG wall $(python -c "import time;print(round(time.time()-$t0,1))") s" | tee -a gpurun_out/${TAG}_bench_${A1:-8}ranks_wall.txt
               cut -c1-300 gpurun_out/${TAG}_bench_line_${A1:-8}ranks_gloo_one_gpu_stagger$SG.json; tail -3 gpurun_out/${TAG}_bench_${A1:-8}ranks_stagger$SG.err
             done ;;
-    cold)   timeout 600 python tools/cold_forward.py --tag $TAG > gpurun_out/${TAG}_cold_forward.jsonl 2> gpurun_out/${TAG}_cold_forward.err; cat gpurun_out/${TAG}_cold_forward.jsonl | cut -c1-260; tail -3 gpurun_out/${TAG}_cold_forward.err ;;
+    cold)   timeout 600 python tools/cold_forward.py --tag $TAG ${A1:+--batches ${A1//,/,}} > gpurun_out/${TAG}_cold_forward.jsonl 2> gpurun_out/${TAG}_cold_forward.err; cat gpurun_out/${TAG}_cold_forward.jsonl | cut -c1-260; tail -3 gpurun_out/${TAG}_cold_forward.err ;;
     train_ref) TAG=$TAG bash tools/train_reference_schedule.sh ;;
+    dpsmooth) for ND in 0 1; do UH_TEST_TEXTURE=smooth UH_TEST_NONDET=$ND timeout 600 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line -k "l1_equals or h_loss" > gpurun_out/${TAG}_pytest_dp_smooth_nondet$ND.log 2>&1; echo "smooth texture, default (non-deterministic) solvers allowed = $ND"; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_smooth_nondet$ND.log | cut -c1-700; done ;;
     dpnoise) UH_TEST_NONDET=1 timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line > gpurun_out/${TAG}_pytest_dp_product_default_solvers.log 2>&1; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_product_default_solvers.log | cut -c1-900 ;;
     power)  timeout 900 python tools/power_ab.py --libs ${A1:-shipped} --kernel ${A2:-bwd} --seconds 4 --reps 2 > gpurun_out/${TAG}_power_${A2:-bwd}.jsonl 2> gpurun_out/${TAG}_power.err; cat gpurun_out/${TAG}_power_${A2:-bwd}.jsonl ;;
     coldv)  : > gpurun_out/${TAG}_cold_forward_variants.jsonl
