@@ -611,11 +611,14 @@ def main():
         t_in = out['roofline']['avg_launch_us']
         temps['in_step_us'] = t_in
         if 'error' not in temps:
-            temps['reading'] = ('the in-step launch costs what the same launch costs after a 1 GiB evicting copy (cold), %.1f us more '
-                                'than back to back (warm): the gap between roofline.frac and the warm figure is COLD INPUT, not grid '
-                                'tail -- t(B) over B = 32..128 is a straight line (profiles/r04_cold_forward.jsonl: residuals <= 0.4 us; '
-                                'fixed 9.5 us + 0.295 us/pair cold = 0.78 x 8 TB/s asymptotically, the float4-copy yardstick)'
-                                % (temps['cold_us'] - temps['warm_us']))
+            span = max(temps['cold_us'] - temps['warm_us'], 1e-9)
+            temps['in_step_position_between_warm_and_cold'] = round((t_in - temps['warm_us']) / span, 3)
+            temps['reading'] = ('the in-step launch (%.1f us) lies %.0f %% of the way from the same launch back to back (warm, %.1f us: U served '
+                                'by the Infinity Cache) to the same launch after a 1 GiB evicting copy (cold, %.1f us): the gap between '
+                                'roofline.frac and the warm figure is COLD INPUT, not grid tail -- t(B) over B = 32..128 is a straight line '
+                                '(profiles/r04_cold_forward.jsonl: residuals <= 0.4 us; cold: fixed 9.5 us + 0.295 us/pair = 0.78 x 8 TB/s '
+                                'asymptotically, the float4-copy yardstick; the fixed part is a third of this launch)'
+                                % (t_in, 100.0 * (t_in - temps['warm_us']) / span, temps['warm_us'], temps['cold_us']))
         out['roofline']['why_in_step_frac_is_below_the_warm_point'] = temps
     if world > 1:
         out['config']['world_size'] = torch.distributed.get_world_size()

@@ -77,7 +77,7 @@ def main():
                     if temp != 'warm':
                         ev_b.copy_(ev_a)                 # 2 x evict_mb of traffic: L2 and Infinity Cache now hold the copy's lines
                     if temp.startswith('cold+readU'):
-                        torch.sum(U, out=sink)
+                        sink.copy_(U.sum())
                     if temp.endswith('fill_out'):
                         out.fill_(0.5)
                     fwd()
