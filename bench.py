@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--rho', type=int, default=45)
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
+    ap.add_argument('--prefetch_frame', type=int, default=1,
+                    help='1: the trainer default -- I is read into the Infinity Cache on a side stream under the regressor\'s tail, '
+                         'the warp then samples a warm frame; 0: off (rounds 1-3)')
     ap.add_argument('--graph_tail', type=int, default=0, help='1: DLT->warp->loss and backward as one hipGraph launch')
     ap.add_argument('--step_graph', type=int, default=0, help='1: whole training step as one hipGraph replay (implies --profile 0)')
     ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object); 1: time the warp kernels; 2: time every library kernel')
@@ -339,7 +342,8 @@ def measure_traffic(args, timeout_s=180):
              '--config4', '1' if args.config4 else '0', '--quality', '0', '--traffic', '0', '--traffic_child', '1', '--profile', '0',
              '--per_gpu_batch', str(args.per_gpu_batch), '--img_h', str(args.img_h), '--img_w', str(args.img_w),
              '--patch_size', str(args.patch_size), '--rho', str(args.rho), '--loss_type', args.loss_type,
-             '--fused_patch', str(args.fused_patch), '--mid_training_theta', str(args.mid_training_theta)]
+             '--fused_patch', str(args.fused_patch), '--mid_training_theta', str(args.mid_training_theta),
+             '--prefetch_frame', str(args.prefetch_frame)]
     vals = {}
     t0 = time.perf_counter()
     with tempfile.TemporaryDirectory(dir='/tmp') as td:
@@ -362,7 +366,7 @@ def measure_traffic(args, timeout_s=180):
             for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
                 for r in csv.DictReader(open(f)):
                     k = r.get('Kernel_Name', '')
-                    if 'uh::warp_' not in k or r.get('Counter_Name') != counter:
+                    if ('uh::warp_' not in k and 'uh::prefetch_kernel' not in k) or r.get('Counter_Name') != counter:
                         continue
                     name = k.replace('void ', '').split('(')[0].replace('uh::', '')
                     wg = int(float(r.get('Workgroup_Size', 256) or 256))
@@ -391,7 +395,7 @@ def traffic_lookup(measured, family, blocks):
     if not measured or 'error' in measured:
         return None
     for k, v in measured.items():
-        if k.startswith(family + '<') and k.endswith('@%d' % blocks) and isinstance(v, dict):
+        if (k.startswith(family + '<') or k.startswith(family + '@')) and k.endswith('@%d' % blocks) and isinstance(v, dict):
             if family == 'warp_backward_kernel' and not k.split('@')[0].endswith(', false>'):
                 continue                                       # PATCH-mode instantiation: the sparse backward of the step
             return v
@@ -429,6 +433,9 @@ def self_launch(args):
 
 def main():
     args = parse()
+    # the pool's host driver only supports dmabuf IPC: without this RCCL / device-tensor sharing across processes fails with
+    # hipIpcGetMemHandle "invalid argument".  Read by the HSA runtime when the first device is opened -- i.e. after this line.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)                                   # does not return
     from unsuperviseddeephomographyral2018_amd import _lib, dist as uh_dist, synthetic
@@ -460,7 +467,8 @@ def main():
         '--mode', 'train', '--loss_type', args.loss_type, '--batch_size', str(B * world),
         '--img_h', str(args.img_h), '--img_w', str(args.img_w), '--patch_size', str(args.patch_size),
         '--rho', str(args.rho), '--fused_patch', 'True' if args.fused_patch else 'False',
-        '--graph_tail', 'True' if args.graph_tail else 'False', '--step_graph', 'True' if args.step_graph else 'False'])
+        '--graph_tail', 'True' if args.graph_tail else 'False', '--step_graph', 'True' if args.step_graph else 'False',
+        '--prefetch_frame', 'True' if args.prefetch_frame else 'False'])
     if args.step_graph:
         args.profile = 0                                    # per-kernel events cannot be inserted into a replayed graph
     step_fn = TrainStep(targs, device, world)
@@ -484,7 +492,7 @@ def main():
         torch.distributed.barrier()
     # profile 1 (default): time only the kernels the roofline object reports -- every timed dispatch costs a small
     # pipeline bubble, and with ~25 library launches per step timing all of them would cost ~10 % of the step
-    hot = ('warp_forward', 'warp_backward', 'warp_backward_finish', 'warp_patch_l1_fused', 'warp_patch_l1_finish')
+    hot = ('warp_forward', 'warp_backward', 'warp_backward_finish', 'warp_patch_l1_fused', 'warp_patch_l1_finish', 'prefetch')
     _lib.profile_enable(bool(args.profile), only=None if args.profile == 2 else hot)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -541,7 +549,11 @@ def main():
         av = step_fn.averager
         # the exchange step on its own (collective, every rank takes part): per-bucket all-reduce time with nothing to hide
         # under, next to the host time finish() spent blocked per step inside the timed region
-        exchange = {'buckets': av.time_buckets(iters=5), 'reduce_op': 'AVG' if av._avg_in_collective else 'SUM+div',
+        try:
+            buckets = av.time_buckets(iters=5)
+        except Exception as e:                              # noqa: BLE001 -- an extra: must not lose the headline
+            buckets = {'error': '%s: %s' % (type(e).__name__, e)}
+        exchange = {'buckets': buckets, 'reduce_op': 'AVG' if av._avg_in_collective else 'SUM+div',
                     'host_blocked_ms_per_step': round(av.exposed_wait_s / max(av.finishes, 1) * 1e3, 4),
                     'note': 'bucket 0 = fc2+fc1 (issued first in backward, overlaps the conv backward), bucket 1 = conv; '
                             'RCCL wait() only enqueues a stream dependency, so host_blocked is ~0 by construction: compare '
@@ -602,6 +614,12 @@ def main():
         'roofline': roofline,
     }
     out['config']['in_step_theta'] = in_step_theta
+    out['config']['frame_prefetch'] = bool(args.prefetch_frame)
+    if args.prefetch_frame and isinstance(out.get('roofline'), dict):
+        out['roofline']['input_state'] = ('I is read into the 256 MB Infinity Cache by uh_prefetch on a side stream while fc2 and the DLT '
+                                         'solve run (--prefetch_frame 1, the trainer default since round 4): the in-step forward samples '
+                                         'a WARM frame; its HBM read traffic moves to the prefetch kernel (roofline.kernels.prefetch, '
+                                         'traffic_prefetch_kernel).  --prefetch_frame 0 reproduces rounds 1-3 (cold frame)')
     out['config']['warmup_seconds'] = round(warmup_s, 1)
     out['config']['miopen_find'] = ('cudnn.benchmark = True; reference solvers excluded from the trials '
                                     '(MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD/BWD/WRW=%s)' % os.environ.get('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'))
@@ -657,6 +675,11 @@ def main():
                 out['roofline']['traffic_stale'] = False
                 out['roofline']['traffic_note'] = mt['_how'] + '; %d launches of the in-step shape seen' % hit['launches_seen']
                 out['roofline']['traffic_over_algorithmic'] = round(hit['hbm_bytes_per_launch'] / alg, 4)
+            pf = traffic_lookup(mt, 'prefetch_kernel', 256)
+            if pf is not None:                                  # the frame's HBM read now happens HERE, under the regressor's tail
+                out['roofline']['traffic_prefetch_kernel'] = pf['hbm_bytes_per_launch']
+                out['roofline']['traffic_forward_plus_prefetch_over_algorithmic'] = round(
+                    (hit['hbm_bytes_per_launch'] if hit else 0) / alg + pf['hbm_bytes_per_launch'] / alg, 4)
         if isinstance(out.get('config4_point'), dict) and 'error' not in out['config4_point']:
             for side, fam in (('traffic_fwd', 'warp_forward_kernel'), ('traffic_bwd', 'warp_backward_kernel')):
                 hit = traffic_lookup(mt, fam, blocks_of(128, 480, 640))

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define UH_ABI_VERSION 4
+#define UH_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define UH_API __attribute__((visibility("default")))
@@ -160,6 +160,13 @@ UH_API int uh_prepare_inputs(const unsigned char* I_u8, const unsigned char* Ipr
                       float* I_aug, float* Iprime_aug, float* I1, float* I2, float* I1_aug, float* I2_aug,
                       int* patch_idx, int B, int H, int W, int P, uh_stream_t stream);
 
+/* ---- Infinity-Cache prefetch of a frame (no reference counterpart: a scheduling hint for the 256 MB memory-side cache) ----
+ * Reads `bytes` bytes at `ptr` once and discards them (a light grid: 256 workgroups of 16-byte loads).  Inside the train step
+ * the frame U was last touched a whole conv stack ago; the same uh_warp_forward launch costs 33 us on a cold U and 20.6 us once
+ * U has been read (profiles/r04_cold_forward_prefetch_probe.jsonl).  Enqueued on a SIDE stream under the fc layers / the DLT
+ * solve, whose kernels leave HBM idle, the read is off the critical path.  Changes no memory; any alignment; bytes may be 0. */
+UH_API int uh_prefetch(const void* ptr, size_t bytes, uh_stream_t stream);
+
 /* ---- all photometric losses in one pass, and the gradient of the trained one ----------------
  * pred, target [B,P,P] (one channel)  ->  out16[16] (device):
  *   [0] rec_loss  [1] ssim_loss  [2] l1_loss  [3] l1_smooth_loss  [4] ncc_loss        homography_model.py:136-166,286-352
@@ -266,7 +273,8 @@ UH_API int    uh_bias_relu_pool_backward(const float* y, const float* gpooled, f
 #define UH_K_EPI_FWD       14
 #define UH_K_EPI_BWD       15
 #define UH_K_LOSS_BWD      16
-#define UH_K_COUNT         17
+#define UH_K_PREFETCH      17
+#define UH_K_COUNT         18
 /* on = 0: off; 1: time every kernel; otherwise a mask: bit (k + 1) set = time kernel UH_K_k only (timing a dispatch
  * costs a few us of pipeline bubble, so a throughput run times just the kernels it reports).  Returns the previous
  * on/off state; resets the counters.                                                                              */

@@ -562,3 +562,48 @@ def test_train_entry_point_from_generator_pool_and_disk(pkg, dev, tmp_path, caps
     assert st.global_step == 12                         # continued from the checkpoint of the previous run
     out = capsys.readouterr().out
     assert '===> Start step: 6' in out
+
+
+def test_frame_prefetch_is_a_hint_same_bits_and_untouched_memory(pkg, dev):
+    """uh_prefetch / ops.prefetch_frame (round 4): reading I into the Infinity Cache on a side stream under the regressor's tail
+    changes no memory and no result -- pred_h4p, H, pred_I2, every loss value and d loss / d pred_h4p are bit-equal with the
+    prefetch on (forked after fc1, or before it) and off; odd pointers / sizes through the C ABI read inside the range only
+    (canaries either side stay intact because nothing is ever written)."""
+    import ctypes as C
+    import os
+    hm, synthetic, _ = pkg
+    from unsuperviseddeephomographyral2018_amd import _lib, ops
+    lib = _lib.load()
+    batch = synthetic.make_batch(B, H, W, P, RHO, seed=31, device=dev)
+    torch.manual_seed(3)
+    net = hm.VGGRegressor(P, dropout_p=0.0).to(dev).to(memory_format=torch.channels_last)
+    keep_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    outs = {}
+    try:
+        for tag, pf, at in (('off', False, 'fc2'), ('after_fc1', True, 'fc2'), ('before_fc1', True, 'fc1')):
+            os.environ['UH_PREFETCH_AT'] = at
+            m = hm.HomographyModel(params(hm, 'train', B, P, W, H, 'l1_loss'), *synthetic.model_args(batch), net=net,
+                                   prefetch_frame=pf)
+            assert m.prefetch_frame == pf
+            (g,) = torch.autograd.grad(m.loss, m.pred_h4p)
+            outs[tag] = [t.detach().clone() for t in (m.pred_h4p, m.H_mat, m.pred_I2, m.l1_loss, m.rec_loss, m.ssim_loss, g)]
+    finally:
+        os.environ.pop('UH_PREFETCH_AT', None)
+        torch.backends.cudnn.deterministic = keep_det
+    torch.cuda.synchronize(dev)
+    for tag in ('after_fc1', 'before_fc1'):
+        for a, b in zip(outs['off'], outs[tag]):
+            assert torch.equal(a, b), tag
+    # the C entry point on ranges that are neither 16-byte aligned nor a multiple of 16 bytes long
+    buf = torch.arange(4096, dtype=torch.float32, device=dev)
+    ref = buf.clone()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for off, nbytes in ((0, 4096 * 4), (4, 4096 * 4 - 8), (12, 37), (8, 0), (4, 15)):
+        _lib.check(lib.uh_prefetch(C.c_void_p(buf.data_ptr() + off), nbytes, st), 'uh_prefetch')
+    ops.prefetch_frame(buf)
+    ops.join_prefetch(dev)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(buf, ref)
+    with pytest.raises(_lib.UHError):
+        ops.prefetch_frame(torch.zeros(4))                       # a host tensor: no CPU fallback, not even for a hint

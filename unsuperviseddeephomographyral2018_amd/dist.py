@@ -26,6 +26,7 @@ import torch.distributed as dist
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
     Returns (rank, world, local_rank).  World size 1 => no process group at all."""
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (the only kind this pool's driver supports) for RCCL
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

@@ -79,6 +79,9 @@ def build_parser():
                    help='train mode: a pair whose d loss / d pred_h4p is NaN / Inf (degenerate predicted corners) contributes '
                         'no gradient instead of poisoning every variable (UH_DLT_ZERO_NONFINITE_GRAD).  False = the '
                         'reference\'s behaviour: tf.matrix_solve + autodiff pass the NaN on.  The log line counts the pairs.')
+    p.add_argument('--prefetch_frame', type=str2bool, default='True',
+                   help='read I into the 256 MB Infinity Cache on a side stream while the regressor\'s last small kernels run, so '
+                        'that the warp samples a warm frame (ops.prefetch_frame / uh_prefetch); a scheduling hint: same bits')
     p.add_argument('--step_graph', type=str2bool, default='False',
                    help='capture the whole training step (convs, hot path, Adam) into one hipGraph and replay it')
     p.add_argument('--graph_tail', type=str2bool, default='False',
@@ -252,7 +255,8 @@ class TrainStep(object):
         self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
-                                h4p_offset=self.h4p_offset, zero_nonfinite_grad=self._zero_nonfinite())
+                                h4p_offset=self.h4p_offset, zero_nonfinite_grad=self._zero_nonfinite(),
+                                prefetch_frame=getattr(self.args, 'prefetch_frame', None))
         model.loss.backward()
         if self.averager is not None:
             self.averager.finish()
@@ -290,7 +294,8 @@ class TrainStep(object):
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
                                 graph_tail=getattr(self.args, 'graph_tail', False), h4p_offset=self.h4p_offset,
-                                zero_nonfinite_grad=self._zero_nonfinite())
+                                zero_nonfinite_grad=self._zero_nonfinite(),
+                                prefetch_frame=getattr(self.args, 'prefetch_frame', None))
         model.loss.backward()
         if self.averager is not None:
             self.averager.finish()

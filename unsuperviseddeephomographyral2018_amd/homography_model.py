@@ -94,7 +94,10 @@ class VGGRegressor(nn.Module):
             x = self.bns[i](x)
         return x
 
-    def forward(self, model_input_nhwc):
+    def forward(self, model_input_nhwc, tail_hook=None, hook_before_fc1=False):
+        """`tail_hook` (optional callable): invoked once where the regressor has only small kernels left to enqueue -- after
+        fc1 (default) or before it -- so that the caller can start side-stream work that overlaps them (HomographyModel: the
+        Infinity-Cache prefetch of the frame the warp will sample).  It must not touch the activations."""
         # [B,P,P,2] NHWC -> NCHW-logical view with channels_last strides (no copy)
         x = model_input_nhwc.permute(0, 3, 1, 2)
         x = self._conv_pool(self._conv(x, 0), 1)
@@ -103,7 +106,11 @@ class VGGRegressor(nn.Module):
         x = self._conv(self._conv(x, 6), 7)
         x = F.dropout(x, self.dropout_p, self.training)
         x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)          # slim.flatten of NHWC
+        if tail_hook is not None and hook_before_fc1:
+            tail_hook()
         x = F.dropout(F.relu(self.fc1(x)), self.dropout_p, self.training)
+        if tail_hook is not None and not hook_before_fc1:
+            tail_hook()
         return self.fc2(x)
 
 
@@ -124,7 +131,7 @@ def reset_variables():
 class HomographyModel(object):
     def __init__(self, args, I1, I2, I1_aug, I2_aug, I_aug, I_prime_aug, h4p, gt, patch_indices,
                  reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False, graph_tail=False,
-                 h4p_offset=None, zero_nonfinite_grad=None):
+                 h4p_offset=None, zero_nonfinite_grad=None, prefetch_frame=None):
         self.params = args
         self.mode = args.mode
         self.is_training = True if self.mode == 'train' else False
@@ -145,6 +152,13 @@ class HomographyModel(object):
         self.fused_patch = fused_patch
         self.solve_f64 = solve_f64
         self.h4p_offset = h4p_offset        # [B,8] added to the regressor's output (bench / test hook; None = off)
+        # Infinity-Cache prefetch of I under the regressor's tail (ops.prefetch_frame): a scheduling hint, bits unchanged.
+        # None = on for device tensors unless UH_PREFETCH_FRAME=0; UH_PREFETCH_AT=fc1 forks before fc1 instead of after it
+        import os
+        if prefetch_frame is None:
+            prefetch_frame = os.environ.get('UH_PREFETCH_FRAME', '1') != '0'
+        self.prefetch_frame = bool(prefetch_frame) and I_aug.is_cuda
+        self._prefetch_before_fc1 = os.environ.get('UH_PREFETCH_AT', 'fc2') == 'fc1'
         # A pair whose predicted corners are degenerate (collinear p2 -> singular 8x8 system -> theta = NaN) must not turn
         # every variable into NaN: in training its d loss / d pred_h4p is zeroed (UH_DLT_ZERO_NONFINITE_GRAD).  The reference
         # has no such guard (tf.matrix_solve raises on a singular system); default = on in train mode.
@@ -185,7 +199,12 @@ class HomographyModel(object):
         self._vgg()
 
     def _vgg(self):
-        self.pred_h4p = self.net(self.model_input)                # BATCH_SIZE x 8
+        if self.prefetch_frame and isinstance(self.net, VGGRegressor):
+            self.pred_h4p = self.net(self.model_input, tail_hook=lambda: ops.prefetch_frame(self.I),
+                                     hook_before_fc1=self._prefetch_before_fc1)
+        else:
+            self.prefetch_frame = False
+            self.pred_h4p = self.net(self.model_input)            # BATCH_SIZE x 8
         if self.h4p_offset is not None:
             self.pred_h4p = self.pred_h4p + self.h4p_offset
 
@@ -193,6 +212,8 @@ class HomographyModel(object):
     def solve_DLT(self):
         self._tail = None
         if self.graph_tail:
+            if self.prefetch_frame:
+                ops.join_prefetch(self.I.device)                   # the tail call below holds the warp
             with torch.set_grad_enabled(self._hot_grad):
                 self._tail = ops.photometric_tail(self.pts_1, self.pred_h4p, self.I, self.I2_aug, self.patch_indices,
                                                   self.params.patch_size, fused_patch=self.fused_patch, graph=True,
@@ -206,6 +227,8 @@ class HomographyModel(object):
 
     # ---- homography_model.py:252-269 ----------------------------------------------------------------
     def transform(self):
+        if self.prefetch_frame:
+            ops.join_prefetch(self.I.device)                       # the side-stream read of I has finished (or: wait for it)
         with torch.set_grad_enabled(self._hot_grad):
             self._transform()
 
