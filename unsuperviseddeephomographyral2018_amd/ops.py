@@ -79,9 +79,13 @@ def prefetch_frame(t):
 
 def join_prefetch(device):
     """Make the current stream wait for the prefetch started by prefetch_frame (no-op if there is none)."""
+    import os
     st = _PREFETCH.get(torch.device(device).index if not isinstance(device, torch.device) else device.index)
     if st is not None and st['done'] is not None:
-        torch.cuda.current_stream(device).wait_event(st['done'])
+        # UH_PREFETCH_JOIN=0 (experiment): fire and forget -- the read-only pass needs no ordering for correctness; only a
+        # stream capture needs the join (unjoined work is a capture error)
+        if os.environ.get('UH_PREFETCH_JOIN', '1') != '0' or torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(device).wait_event(st['done'])
         st['done'] = None
 
 
