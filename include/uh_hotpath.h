@@ -166,6 +166,12 @@ UH_API int uh_prepare_inputs(const unsigned char* I_u8, const unsigned char* Ipr
  * U has been read (profiles/r04_cold_forward_prefetch_probe.jsonl).  Enqueued on a SIDE stream under the fc layers / the DLT
  * solve, whose kernels leave HBM idle, the read is off the critical path.  Changes no memory; any alignment; bytes may be 0. */
 UH_API int uh_prefetch(const void* ptr, size_t bytes, uh_stream_t stream);
+/* The same on a library-owned non-blocking SIDE stream of the current device: the pass starts after the work enqueued on
+ * `stream` so far (fork) and runs beside what `stream` is given next; uh_prefetch_join makes `stream` wait for it (no-op when
+ * nothing is pending; optional -- the pass only reads).  Fork and join use events without the system-scope fence.  Inside a
+ * stream capture uh_prefetch_async does nothing (a hint may be dropped).  One prefetch in flight per device.                */
+UH_API int uh_prefetch_async(const void* ptr, size_t bytes, uh_stream_t stream);
+UH_API int uh_prefetch_join(uh_stream_t stream);
 
 /* ---- all photometric losses in one pass, and the gradient of the trained one ----------------
  * pred, target [B,P,P] (one channel)  ->  out16[16] (device):

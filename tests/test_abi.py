@@ -80,7 +80,7 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert b'UH_E_WORKSPACE' in lib.uh_error_string(-4)
     assert lib.uh_kernel_name(2) == b'warp_forward'
     # uh_prefetch (round 4): NULL refused; a range that holds no whole 16-byte chunk is a no-op that launches nothing
-    assert lib.uh_prefetch(None, 4096, None) == -1
+    assert lib.uh_prefetch(None, 4096, None) == -1 and lib.uh_prefetch_async(None, 4096, None) == -1
     assert lib.uh_prefetch(one, 0, None) == 0 and lib.uh_prefetch(C.c_void_p(1), 30, None) == 0
     assert lib.uh_kernel_name(17) == b'prefetch' and lib.uh_kernel_name(18) == b'?'
     # entry points added after the first slice

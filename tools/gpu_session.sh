@@ -82,12 +82,17 @@ for ST in "$@"; do
     cold)   timeout 600 python tools/cold_forward.py --tag $TAG ${A1:+--batches ${A1//,/,}} > gpurun_out/${TAG}_cold_forward.jsonl 2> gpurun_out/${TAG}_cold_forward.err; cat gpurun_out/${TAG}_cold_forward.jsonl | cut -c1-260; tail -3 gpurun_out/${TAG}_cold_forward.err ;;
     train_ref) TAG=$TAG bash tools/train_reference_schedule.sh ;;
     prefetch_ab) : > gpurun_out/${TAG}_prefetch_ab.jsonl
-            for rep in 1 2; do for V in "0 fc2 1" "1 fc2 1" "1 fc2 0"; do set -- $V
-              UH_PREFETCH_AT=$2 UH_PREFETCH_JOIN=$3 timeout 400 python bench.py --prefetch_frame $1 --profile ${PROFILE:-1} --steps 60 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --traffic 0 2>/dev/null | python -c "
+            # prefetch on/off, join / fire-and-forget, and the profiler's events with / without the system-scope fence
+            for rep in 1 2; do for V in "0 1 0" "1 1 0" "1 0 0" "0 1 1"; do set -- $V
+              UH_PREFETCH_JOIN=$2 UH_PROF_FENCE=$3 timeout 400 python bench.py --prefetch_frame $1 --profile ${PROFILE:-1} --steps 60 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --traffic 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); k=d['roofline']['kernels']
-print(json.dumps({'prefetch': $1, 'at': '$2', 'join': $3, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step'], 'frac': d['roofline']['frac'], 'us': {n: k[n]['avg_us'] for n in k if n in ('warp_forward','warp_backward','warp_backward_finish','patch_losses','patch_losses_finish','dlt_forward','dlt_backward','prefetch')}, 'temps': {a: b for a, b in (d['roofline'].get('why_in_step_frac_is_below_the_warm_point') or {}).items() if a.endswith('_us')}}))" >> gpurun_out/${TAG}_prefetch_ab.jsonl
-            done; done; cat gpurun_out/${TAG}_prefetch_ab.jsonl ;;
+print(json.dumps({'prefetch': $1, 'join': $2, 'prof_fence': $3, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step'], 'frac': d['roofline']['frac'], 'us': {n: k[n]['avg_us'] for n in k if n in ('warp_forward','warp_backward','warp_backward_finish','prefetch')}, 'temps': {a: b for a, b in (d['roofline'].get('why_in_step_frac_is_below_the_warm_point') or {}).items() if a.endswith('_us')}}))" >> gpurun_out/${TAG}_prefetch_ab.jsonl
+            done; done
+            for P0 in 0 1; do timeout 400 python bench.py --prefetch_frame $P0 --profile 0 --steps 60 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --traffic 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print(json.dumps({'prefetch': $P0, 'profile': 0, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step']}))" >> gpurun_out/${TAG}_prefetch_ab.jsonl; done
+            cat gpurun_out/${TAG}_prefetch_ab.jsonl ;;
     dpsmooth) for ND in 0 1; do UH_TEST_TEXTURE=smooth UH_TEST_NONDET=$ND timeout 600 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line -k "l1_equals or h_loss" > gpurun_out/${TAG}_pytest_dp_smooth_nondet$ND.log 2>&1; echo "smooth texture, default (non-deterministic) solvers allowed = $ND"; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_smooth_nondet$ND.log | cut -c1-700; done ;;
     dpnoise) UH_TEST_NONDET=1 timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line > gpurun_out/${TAG}_pytest_dp_product_default_solvers.log 2>&1; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_product_default_solvers.log | cut -c1-900 ;;
     power)  timeout 900 python tools/power_ab.py --libs ${A1:-shipped} --kernel ${A2:-bwd} --seconds 4 --reps 2 > gpurun_out/${TAG}_power_${A2:-bwd}.jsonl 2> gpurun_out/${TAG}_power.err; cat gpurun_out/${TAG}_power_${A2:-bwd}.jsonl ;;

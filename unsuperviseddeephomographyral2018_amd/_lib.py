@@ -43,6 +43,8 @@ SIGNATURES = {
     'uh_l1_loss_backward': (_i, [_p, _p, _p, _p, _z, _p]),
     'uh_prepare_inputs': (_i, [_p] * 13 + [_i, _i, _i, _i, _p]),
     'uh_prefetch': (_i, [_p, _z, _p]),
+    'uh_prefetch_async': (_i, [_p, _z, _p]),
+    'uh_prefetch_join': (_i, [_p]),
     'uh_patch_losses_workspace_bytes': (_z, [_i, _i]),
     'uh_patch_losses_forward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     'uh_patch_loss_backward': (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p]),

@@ -8,6 +8,7 @@
 // solve_DLT -> transform -> l1_loss chain runs in this library without a torch op in between.
 #include "uh_device.h"
 #include "uh_host.h"
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -132,7 +133,11 @@ double g_ms[UH_K_COUNT];
 long long g_n[UH_K_COUNT];
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
-    hipEvent_t e; (void)hipEventCreate(&e); return e;
+    // Timing-only events: without the system-scope fence a default event performs when it completes (a cache writeback +
+    // invalidate that perturbs the very kernels being timed -- hip_runtime_api.h on hipEventDisableSystemFence).
+    // UH_PROF_FENCE=1 restores default events (rounds 1-3) for an A/B.
+    static const bool fence = [] { const char* v = getenv("UH_PROF_FENCE"); return v && v[0] == '1'; }();
+    hipEvent_t e; (void)hipEventCreateWithFlags(&e, fence ? hipEventDefault : hipEventDisableSystemFence); return e;
 }
 }  // namespace
 
@@ -189,6 +194,58 @@ extern "C" int uh_prefetch(const void* ptr, size_t bytes, uh_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     launch_timed(UH_K_PREFETCH, prefetch_kernel, dim3(256), dim3(256), s, (const uint4*)a, n16, (unsigned*)nullptr);
     return (int)hipGetLastError();
+}
+
+// ---- the same on a library-owned SIDE stream, forked from / joined to the caller's stream ----------------------------------
+// Fork and join are events WITHOUT the system-scope fence (hipEventDisableTiming | hipEventDisableSystemFence): a default event
+// writes back and invalidates the caches when it completes, which cost the train step ~70 us per prefetch when the same
+// fork / join was built from torch's default events (profiles/r04_prefetch_ab.jsonl) -- ten times what the prefetch saves.
+namespace {
+struct SideState { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, done = nullptr; bool pending = false; };
+SideState g_side[64];
+std::mutex g_side_mu;
+int side_state(SideState** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return UH_E_SHAPE;
+    SideState& st = g_side[dev];
+    if (!st.stream) {
+        if ((e = hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking)) != hipSuccess) return (int)e;
+        const unsigned fl = hipEventDisableTiming | hipEventDisableSystemFence;
+        if ((e = hipEventCreateWithFlags(&st.fork, fl)) != hipSuccess) return (int)e;
+        if ((e = hipEventCreateWithFlags(&st.done, fl)) != hipSuccess) return (int)e;
+    }
+    *out = &st;
+    return 0;
+}
+}  // namespace
+
+extern "C" int uh_prefetch_async(const void* ptr, size_t bytes, uh_stream_t stream) {
+    if (!ptr) return UH_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return 0;                                   // a hint: inside a stream capture it is simply not given
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideState* st = nullptr;
+    if (int e = side_state(&st)) return e;
+    hipError_t e;
+    if ((e = hipEventRecord(st->fork, s)) != hipSuccess) return (int)e;            // fork: after the caller's work so far
+    if ((e = hipStreamWaitEvent(st->stream, st->fork, 0)) != hipSuccess) return (int)e;
+    if (int r = uh_prefetch(ptr, bytes, (uh_stream_t)st->stream)) return r;
+    if ((e = hipEventRecord(st->done, st->stream)) != hipSuccess) return (int)e;
+    st->pending = true;
+    return 0;
+}
+
+extern "C" int uh_prefetch_join(uh_stream_t stream) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideState* st = nullptr;
+    if (int e = side_state(&st)) return e;
+    if (!st->pending) return 0;
+    st->pending = false;
+    return (int)hipStreamWaitEvent((hipStream_t)stream, st->done, 0);
 }
 
 extern "C" int uh_abi_version(void) { return UH_ABI_VERSION; }

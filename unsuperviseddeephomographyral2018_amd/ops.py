@@ -55,38 +55,25 @@ def m_and_minv(img_w, img_h):
 # step `I` was last touched a whole conv stack ago: uh_warp_forward then costs 27 - 33 us instead of the 18 - 21 us it costs
 # on a frame that has just been read.  The read-and-discard pass is enqueued on a SIDE stream, forked from the current stream
 # where the regressor has only its small tail left to run (fc2, the DLT solve: kernels that leave HBM idle) and joined again
-# right before the warp -- fork / join by events, so the pattern is legal inside a hipGraph capture as well.
-_PREFETCH = {}
-
-
+# right before the warp.  The side stream and the two events live in the library (uh_prefetch_async / uh_prefetch_join).
 def prefetch_frame(t):
-    """Start reading `t` (a device tensor; its storage is not modified) into the memory-side cache on a side stream."""
+    """Start reading `t` (a device tensor; its storage is not modified) into the memory-side cache on the library's side stream
+    (uh_prefetch_async: fork from the current stream by an event without the system-scope fence)."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.UHError('prefetch_frame: a tensor on the HIP device is required (got %s)' % getattr(t, 'device', type(t)))
-    lib = _lib.load()
-    dev = t.device
-    st = _PREFETCH.get(dev.index)
-    if st is None:
-        st = _PREFETCH[dev.index] = {'stream': torch.cuda.Stream(device=dev), 'done': None}
-    side = st['stream']
-    side.wait_stream(torch.cuda.current_stream(dev))                 # fork: after everything enqueued so far
     nbytes = t.numel() * t.element_size() if t.is_contiguous() else 0
-    _lib.check(lib.uh_prefetch(C.c_void_p(t.data_ptr()), nbytes, C.c_void_p(side.cuda_stream)), 'uh_prefetch')
-    ev = torch.cuda.Event()
-    ev.record(side)
-    st['done'] = ev
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().uh_prefetch_async(C.c_void_p(t.data_ptr()), nbytes,
+                                                 C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)), 'uh_prefetch_async')
 
 
 def join_prefetch(device):
     """Make the current stream wait for the prefetch started by prefetch_frame (no-op if there is none)."""
     import os
-    st = _PREFETCH.get(torch.device(device).index if not isinstance(device, torch.device) else device.index)
-    if st is not None and st['done'] is not None:
-        # UH_PREFETCH_JOIN=0 (experiment): fire and forget -- the read-only pass needs no ordering for correctness; only a
-        # stream capture needs the join (unjoined work is a capture error)
-        if os.environ.get('UH_PREFETCH_JOIN', '1') != '0' or torch.cuda.is_current_stream_capturing():
-            torch.cuda.current_stream(device).wait_event(st['done'])
-        st['done'] = None
+    if os.environ.get('UH_PREFETCH_JOIN', '1') == '0':          # experiment: fire and forget (the pass only reads)
+        return
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().uh_prefetch_join(C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), 'uh_prefetch_join')
 
 
 # ------------------------------------------------------------------------------------------------
