@@ -52,9 +52,9 @@ def parse():
     ap.add_argument('--rho', type=int, default=45)
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
-    ap.add_argument('--prefetch_frame', type=int, default=1,
-                    help='1: the trainer default -- I is read into the Infinity Cache on a side stream under the regressor\'s tail, '
-                         'the warp then samples a warm frame; 0: off (rounds 1-3)')
+    ap.add_argument('--prefetch_frame', type=int, default=0,
+                    help='1: I is read into the Infinity Cache on a side stream under the regressor\'s tail, the warp then samples a '
+                         'warm frame (faster kernel, slower step: see roofline.with_frame_prefetch); 0: the trainer default')
     ap.add_argument('--graph_tail', type=int, default=0, help='1: DLT->warp->loss and backward as one hipGraph launch')
     ap.add_argument('--step_graph', type=int, default=0, help='1: whole training step as one hipGraph replay (implies --profile 0)')
     ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object); 1: time the warp kernels; 2: time every library kernel')
@@ -540,6 +540,39 @@ def main():
             temps = forward_temperatures(device, batch['I_aug'], th_last, args.img_h, args.img_w)
         except Exception as e:                              # noqa: BLE001 -- an extra, must not lose the headline
             temps = {'error': '%s: %s' % (type(e).__name__, e)}
+    # The measured remedy for the cold frame, and why it is not the default (round 4): a few untimed steps with the frame
+    # prefetched on the library's side stream -- kernel durations by dispatch events, then step time with and without, events off.
+    with_pf = None
+    if args.profile and world == 1 and not args.step_graph and not args.fused_patch and not args.traffic_child and not args.prefetch_frame:
+        try:
+            def steps_ms(n):
+                torch.cuda.synchronize(device)
+                t_a = time.perf_counter()
+                for _ in range(n):
+                    step_fn(batch)
+                torch.cuda.synchronize(device)
+                return (time.perf_counter() - t_a) / n * 1e3
+            step_fn.args.prefetch_frame = True
+            steps_ms(3)
+            _lib.profile_enable(True, only=('warp_forward', 'prefetch'))
+            steps_ms(10)
+            p3 = _lib.profile_read()
+            _lib.profile_enable(False)
+            ms_on = steps_ms(20)
+            step_fn.args.prefetch_frame = False
+            steps_ms(3)
+            ms_off = steps_ms(20)
+            us3 = p3['warp_forward'][0] / max(p3['warp_forward'][1], 1) * 1e3
+            with_pf = {'warp_forward_avg_us': round(us3, 2),
+                       'frac': round(2 * B * args.img_h * args.img_w * 3 * 4 / (us3 * 1e-6) / HBM_PEAK, 4),
+                       'prefetch_kernel_avg_us': round(p3['prefetch'][0] / max(p3['prefetch'][1], 1) * 1e3, 2),
+                       'ms_per_step_with_prefetch': round(ms_on, 3), 'ms_per_step_without': round(ms_off, 3),
+                       'note': '--prefetch_frame True (ops.prefetch_frame: uh_prefetch_async reads I into the Infinity Cache on a side stream '
+                               'after fc1; the warp samples a warm frame).  NOT the default: the second active HW queue costs the step more '
+                               'than the warm frame saves.  10 + 20 + 20 untimed steps after the timed region, same batch, same theta law'}
+        except Exception as e:                              # noqa: BLE001 -- an extra, must not lose the headline
+            step_fn.args.prefetch_frame = False
+            with_pf = {'error': '%s: %s' % (type(e).__name__, e)}
     loss_val = float(model.loss.detach())
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -616,10 +649,10 @@ def main():
     out['config']['in_step_theta'] = in_step_theta
     out['config']['frame_prefetch'] = bool(args.prefetch_frame)
     if args.prefetch_frame and isinstance(out.get('roofline'), dict):
-        out['roofline']['input_state'] = ('I is read into the 256 MB Infinity Cache by uh_prefetch on a side stream while fc2 and the DLT '
-                                         'solve run (--prefetch_frame 1, the trainer default since round 4): the in-step forward samples '
-                                         'a WARM frame; its HBM read traffic moves to the prefetch kernel (roofline.kernels.prefetch, '
-                                         'traffic_prefetch_kernel).  --prefetch_frame 0 reproduces rounds 1-3 (cold frame)')
+        out['roofline']['input_state'] = ('NOT the trainer default: I is read into the 256 MB Infinity Cache by uh_prefetch_async on a side '
+                                         'stream while fc2 and the DLT solve run (--prefetch_frame 1): the in-step forward samples a WARM '
+                                         'frame; its HBM read traffic moves to the prefetch kernel (roofline.kernels.prefetch, '
+                                         'traffic_prefetch_kernel)')
     out['config']['warmup_seconds'] = round(warmup_s, 1)
     out['config']['miopen_find'] = ('cudnn.benchmark = True; reference solvers excluded from the trials '
                                     '(MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD/BWD/WRW=%s)' % os.environ.get('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'))
@@ -638,6 +671,8 @@ def main():
                                 'asymptotically, the float4-copy yardstick; the fixed part is a third of this launch)'
                                 % (t_in, 100.0 * (t_in - temps['warm_us']) / span, temps['warm_us'], temps['cold_us']))
         out['roofline']['why_in_step_frac_is_below_the_warm_point'] = temps
+    if with_pf is not None and isinstance(out.get('roofline'), dict):
+        out['roofline']['with_frame_prefetch'] = with_pf
     if world > 1:
         out['config']['world_size'] = torch.distributed.get_world_size()
         out['config']['dist_backend'] = torch.distributed.get_backend()
@@ -693,7 +728,10 @@ def main():
         torch.cuda.empty_cache()
         out['quality'] = guarded(quality_run, device, args)
     out['timing_note'] = ('per-dispatch HIP events on the warp kernels inside the timed region (--profile 1) cost a small pipeline '
-                          'bubble each: the headline is understated by ~0.5 %% (measured with --profile 0)') if args.profile else None
+                          'bubble each: the headline is understated by ~0.3 % (measured with --profile 0).  Since round 4 the events are '
+                          'created with hipEventDisableSystemFence: a default event writes back and invalidates the caches when it completes, '
+                          'which made rounds 1-3 read the in-step forward ~1 us and the sparse backward ~1.4 us too long '
+                          '(UH_PROF_FENCE=1 restores that; profiles/r04_prefetch_ab_library_side_stream.jsonl)') if args.profile else None
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

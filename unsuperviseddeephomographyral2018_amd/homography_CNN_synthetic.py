@@ -79,9 +79,10 @@ def build_parser():
                    help='train mode: a pair whose d loss / d pred_h4p is NaN / Inf (degenerate predicted corners) contributes '
                         'no gradient instead of poisoning every variable (UH_DLT_ZERO_NONFINITE_GRAD).  False = the '
                         'reference\'s behaviour: tf.matrix_solve + autodiff pass the NaN on.  The log line counts the pairs.')
-    p.add_argument('--prefetch_frame', type=str2bool, default='True',
+    p.add_argument('--prefetch_frame', type=str2bool, default='False',
                    help='read I into the 256 MB Infinity Cache on a side stream while the regressor\'s last small kernels run, so '
-                        'that the warp samples a warm frame (ops.prefetch_frame / uh_prefetch); a scheduling hint: same bits')
+                        'that the warp samples a warm frame (ops.prefetch_frame / uh_prefetch_async); same bits.  Off by default: '
+                        'the warp forward gets 9 us faster, the step 60 - 90 us slower (a second active HW queue)')
     p.add_argument('--step_graph', type=str2bool, default='False',
                    help='capture the whole training step (convs, hot path, Adam) into one hipGraph and replay it')
     p.add_argument('--graph_tail', type=str2bool, default='False',

@@ -153,10 +153,12 @@ class HomographyModel(object):
         self.solve_f64 = solve_f64
         self.h4p_offset = h4p_offset        # [B,8] added to the regressor's output (bench / test hook; None = off)
         # Infinity-Cache prefetch of I under the regressor's tail (ops.prefetch_frame): a scheduling hint, bits unchanged.
-        # None = on for device tensors unless UH_PREFETCH_FRAME=0; UH_PREFETCH_AT=fc1 forks before fc1 instead of after it
+        # OFF by default: it takes the in-step warp forward from 27.5 to 18.8 us (0.54 -> 0.79 of the roofline), but a second
+        # active HW queue costs the step 60 - 90 us -- ten times what the warm frame saves (DESIGN.md 3.1 "Round 4",
+        # profiles/r04_prefetch_ab_*.jsonl).  None = UH_PREFETCH_FRAME (default 0); UH_PREFETCH_AT=fc1 forks before fc1
         import os
         if prefetch_frame is None:
-            prefetch_frame = os.environ.get('UH_PREFETCH_FRAME', '1') != '0'
+            prefetch_frame = os.environ.get('UH_PREFETCH_FRAME', '0') == '1'
         self.prefetch_frame = bool(prefetch_frame) and I_aug.is_cuda
         self._prefetch_before_fc1 = os.environ.get('UH_PREFETCH_AT', 'fc2') == 'fc1'
         # A pair whose predicted corners are degenerate (collinear p2 -> singular 8x8 system -> theta = NaN) must not turn
