@@ -482,10 +482,6 @@ def main():
     if args.mid_training_theta:
         g = torch.Generator(device=device).manual_seed(4321 + rank)
         step_fn.h4p_offset = batch['gt'] + 2.0 * torch.randn(B, 8, generator=g, device=device)
-    if os.environ.get('UH_BENCH_STREAM') == '1':            # experiment: the whole run on a non-NULL stream
-        _bench_stream = torch.cuda.Stream(device=device)
-        _bench_stream.wait_stream(torch.cuda.current_stream(device))
-        torch.cuda.set_stream(_bench_stream)
     find_pass_s = step_fn.prime_conv_finds(batch)           # world > 1: MIOpen find by rank 0 first (untimed, before the warm-up)
     t_w = time.perf_counter()
     for _ in range(args.warmup):

@@ -93,12 +93,6 @@ print(json.dumps({'prefetch': $1, 'join': $2, 'prof_fence': $3, 'pairs_s': d['va
 import json,sys
 d=json.loads(sys.stdin.readline()); print(json.dumps({'prefetch': $P0, 'profile': 0, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step']}))" >> gpurun_out/${TAG}_prefetch_ab.jsonl; done
             cat gpurun_out/${TAG}_prefetch_ab.jsonl ;;
-    prefetch_stream) : > gpurun_out/${TAG}_prefetch_stream.jsonl
-            for rep in 1 2; do for V in "0 0" "1 0" "0 1" "1 1"; do set -- $V
-              UH_BENCH_STREAM=$2 timeout 400 python bench.py --prefetch_frame $1 --profile 0 --steps 80 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --traffic 0 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print(json.dumps({'prefetch': $1, 'non_null_stream': $2, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step']}))" >> gpurun_out/${TAG}_prefetch_stream.jsonl
-            done; done; cat gpurun_out/${TAG}_prefetch_stream.jsonl ;;
     dpsmooth) for ND in 0 1; do UH_TEST_TEXTURE=smooth UH_TEST_NONDET=$ND timeout 600 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line -k "l1_equals or h_loss" > gpurun_out/${TAG}_pytest_dp_smooth_nondet$ND.log 2>&1; echo "smooth texture, default (non-deterministic) solvers allowed = $ND"; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_smooth_nondet$ND.log | cut -c1-700; done ;;
     dpnoise) UH_TEST_NONDET=1 timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line > gpurun_out/${TAG}_pytest_dp_product_default_solvers.log 2>&1; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_product_default_solvers.log | cut -c1-900 ;;
     power)  timeout 900 python tools/power_ab.py --libs ${A1:-shipped} --kernel ${A2:-bwd} --seconds 4 --reps 2 > gpurun_out/${TAG}_power_${A2:-bwd}.jsonl 2> gpurun_out/${TAG}_power.err; cat gpurun_out/${TAG}_power_${A2:-bwd}.jsonl ;;
