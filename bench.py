@@ -164,7 +164,22 @@ def quality_run(device, args):
             'data': 'synthetic %s texture, pool of %d batches cycled in random order; test: %d held-out pairs x 3 passes '
                     '(reference: MS-COCO crops, 150 000 steps)' % (args.quality_texture, args.quality_pool, 1024),
             'note': 'fixed step budget (%d of the reference\'s 150 000 steps): not a converged model; longer runs under profiles/'
-                    % args.quality_steps}
+                    % args.quality_steps,
+            'reference_schedule_run': reference_schedule_result()}
+
+
+def reference_schedule_result():
+    """The committed result of the ONE run at the reference's own schedule (150 000 steps, lr 1e-4; tools/train_reference_schedule.sh)
+    -- read from profiles/, NOT measured in this run (it takes 14 GPU-minutes)."""
+    import re
+    f = os.path.join(ROOT, 'profiles', 'r04_train_reference_schedule.txt')
+    try:
+        txt = open(f).read()
+        m = re.search(r'Average error: ([0-9.]+) \|Fail percent: ([0-9.]+)', txt)
+        return {'mean_corner_error_px': float(m.group(1)), 'fail_percent': float(m.group(2)), 'train_steps': 150000,
+                'file': 'profiles/r04_train_reference_schedule.txt', 'note': 'read from the committed log, not measured in this run'}
+    except Exception:
+        return None
 
 
 def tile_paths(theta, H, W, lds_bytes=5120, tile=16):
