@@ -5,8 +5,7 @@ and its one warp_forward row averages three theta laws).
 
 A step is the span from one uh::dlt_forward_kernel<float> launch to the next that also holds a uh::dlt_backward launch
 (the stand-alone DLT solves bench.py makes for its statistics hold none).  Steps W .. W+K-1 are the timed region (mid-training
-theta law); the last 8 steps of the run are the "round-1 law" replay (raw regressor, near identity).  What follows the last
-step (warm / cold replays of the forward) is reported as a third block.
+theta law); then come the untimed replays bench.py appends: the round-1 law, and (round 4) the frame prefetch on / off.
 
 usage: timed_steps_stats.py kernel_trace.csv W K > profiles/rNN_bench_kernel_stats_timed_steps.csv
 """
@@ -25,12 +24,15 @@ for a, b in zip(marks, marks[1:] + [len(rows)]):
         spans.append((a, b))
 if len(spans) < W + K:
     sys.exit('only %d steps found, need warm-up %d + timed %d' % (len(spans), W, K))
+# What bench.py runs after the timed region (all untimed): 2 + 8 steps under the round-1 law (raw regressor), then -- round 4 --
+# 3 + 10 + 20 steps with the frame prefetch on and 3 + 20 with it off again (mid-training law).
 blocks = [('timed steps (mid-training theta law: regressor + gt + N(0,2px))', spans[W:W + K])]
 extra = spans[W + K:]
-if len(extra) >= 8:
-    blocks.append(('replay under the round-1 law (raw regressor, near identity), last 8 steps', extra[-8:]))
-# a last block: whatever runs after the final step's span start + its own kernels -> only the warp forward replays matter
-last_b = spans[-1][1]
+if len(extra) >= 10:
+    blocks.append(('replay under the round-1 law (raw regressor, near identity), 8 steps', extra[2:10]))
+if len(extra) >= 10 + 33 + 23:
+    blocks.append(('mid-training law WITH the frame prefetch (--prefetch_frame True), 30 steps', extra[13:43]))
+    blocks.append(('mid-training law, prefetch off again, 20 steps', extra[46:66]))
 out = csv.writer(sys.stdout)
 out.writerow(['Block', 'Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'MinNs', 'MaxNs', 'UsPerStep', 'Steps'])
 for label, sp in blocks:
