@@ -433,13 +433,16 @@ def test_conv_bias_relu_epilogue_equals_torch(pkg, dev):
         assert (ga - gb).abs().max() <= (1e-3 if tight else 5e-2) * max(1e-6, float(gb.abs().max())), n
 
 
-def test_whole_step_hipgraph_trains(pkg, dev):
+@pytest.mark.parametrize('prefetch', ['False', 'True'])
+def test_whole_step_hipgraph_trains(pkg, dev, prefetch):
     """--step_graph: the whole training step (convs, epilogues, hot path, capturable fused Adam) captured into one
     hipGraph and replayed.  The replayed steps must keep training (loss on a fixed batch goes down) and new batch data
-    copied into the static buffers must be what the graph consumes."""
+    copied into the static buffers must be what the graph consumes.  With --prefetch_frame True the side-stream hint is given
+    in the eager warm-up steps and silently dropped inside the capture (uh_prefetch_async under a capturing stream)."""
     hm, synthetic, drv = pkg
     args = drv.build_parser().parse_args(['--batch_size', str(B), '--img_h', str(H), '--img_w', str(W), '--patch_size', str(P),
-                                          '--rho', str(RHO), '--loss_type', 'l1_loss', '--step_graph', 'True', '--lr', '1e-4'])
+                                          '--rho', str(RHO), '--loss_type', 'l1_loss', '--step_graph', 'True', '--lr', '1e-4',
+                                          '--prefetch_frame', prefetch])
     torch.manual_seed(0)
     step = drv.TrainStep(args, dev, 1)
     batch = synthetic.make_batch(B, H, W, P, RHO, seed=21, device=dev)
