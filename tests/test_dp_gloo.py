@@ -229,3 +229,29 @@ def test_grad_averager_disabled_issues_no_collective():
     avg.reset()
     with pytest.raises(Exception):
         net(torch.randn(4, 2, 8, 8)).sum().backward()  # enabled: the hook reaches for the (absent) process group
+
+
+def test_gloo_group_formation_keeps_stdout_clean():
+    """bench.py's contract is ONE JSON line on stdout.  gloo's C++ side prints "[Gloo] Rank r is connected to n peer ranks" on
+    stdout when the group forms (seen in the first 8-rank dry run of round 4): dist.init_from_env points fd 1 at stderr while
+    that happens.  Two real ranks, each prints one line of its own after joining: nothing else may reach stdout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'from unsuperviseddeephomographyral2018_amd import dist as D\n'
+            'import torch, torch.distributed as dist\n'
+            'r, w, l = D.init_from_env(backend="gloo")\n'
+            't = torch.ones(4) * (r + 1); dist.all_reduce(t)\n'
+            'print("RANK %%d OF %%d SUM %%d" %% (r, w, int(t[0])), flush=True)\n'
+            'dist.destroy_process_group()\n' % root)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+        procs.append(subprocess.Popen([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, se[-2000:]
+        assert so == 'RANK %d OF 2 SUM 3\n' % r, 'stdout of rank %d is not clean: %r' % (r, so)
