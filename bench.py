@@ -168,6 +168,18 @@ def quality_run(device, args):
             'reference_schedule_run': reference_schedule_result()}
 
 
+def regressor_flops(P):
+    """Forward FLOPs per pair of the VGG regressor (homography_model.py:107-133) on a P x P patch: 3x3 convs 2->64->64 at P,
+    64->64->64 at P/2, 64->128->128 at P/4, 128->128->128 at P/8, fc (P/8)^2*128 -> 1024 -> 8.  2.52 GFLOP at P = 128."""
+    f, side = 0, P
+    for chans in ([(2, 64), (64, 64)], [(64, 64), (64, 64)], [(64, 128), (128, 128)], [(128, 128), (128, 128)]):
+        for ci, co in chans:
+            f += 2 * side * side * ci * co * 9
+        side //= 2
+    side *= 2                                                 # no pool after the last block
+    return f + 2 * side * side * 128 * 1024 + 2 * 1024 * 8
+
+
 def reference_schedule_result():
     """The committed result of the ONE run at the reference's own schedule (150 000 steps, lr 1e-4; tools/train_reference_schedule.sh)
     -- read from profiles/, NOT measured in this run (it takes 14 GPU-minutes)."""
@@ -675,6 +687,14 @@ def main():
         'roofline': roofline,
     }
     out['config']['in_step_theta'] = in_step_theta
+    # where the HEADLINE stands against its own roofline: the step is conv GEMMs (stock MIOpen f32 igemm on f32-input MFMA)
+    step_flops = 3 * regressor_flops(args.patch_size) * global_batch
+    out['headline_roofline'] = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': 157.3, 'achieved': round(step_flops / dt * args.steps / 1e12, 1),
+                                'frac': round(step_flops / dt * args.steps / 1e12 / (157.3 * world), 4),
+                                'flops_per_step': step_flops,
+                                'note': 'whole train step (3 x forward FLOPs of the VGG regressor x global batch) / ms_per_step against the f32-input '
+                                        'MFMA peak per GPU (v_mfma_f32_32x32x2_f32 = the f32 vector rate; gfx950 has no xf32 / TF32): the conv '
+                                        'stack is stock MIOpen by north_star, the hand-written hot path is 1.5 % of the step'}
     out['config']['frame_prefetch'] = bool(args.prefetch_frame)
     if args.prefetch_frame and isinstance(out.get('roofline'), dict):
         out['roofline']['input_state'] = ('NOT the trainer default: I is read into the 256 MB Infinity Cache by uh_prefetch_async on a side '

@@ -122,3 +122,9 @@ def test_timed_steps_stats_blocks(tmp_path):
     assert got['mid-training'][1] in (18700.0, 27700.0) and len(got) >= 3
     blocks = {row['Block'] for row in csv.DictReader(io.StringIO(r.stdout))}
     assert any('WITH the frame prefetch' in b for b in blocks) and any('prefetch off again' in b for b in blocks)
+
+
+def test_regressor_flops_match_the_survey(bench):
+    """2.52 GFLOP forward per pair at P = 128 (block1 1.246, block2 0.604, block3 0.453, block4 0.151, fc 0.067)."""
+    assert abs(bench.regressor_flops(128) / 1e9 - 2.52) < 0.005
+    assert bench.regressor_flops(64) < bench.regressor_flops(128) / 3.9
