@@ -365,6 +365,9 @@ def measure_traffic(args, timeout_s=180):
     tool = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(tool):
         return {'error': 'rocprofv3 not found'}
+    nested = sorted(k for k in os.environ if k.startswith(('ROCPROF', 'ROCP_', 'ROCTRACER', 'RPD_')))
+    if nested:                                               # this process is itself being profiled: no profiler inside a profiler
+        return {'error': 'running under a profiler (%s): PMC child passes skipped' % ', '.join(nested[:3])}
     child = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '3', '--cpu_baseline', '0', '--north_star', '0',
              '--config4', '1' if args.config4 else '0', '--quality', '0', '--traffic', '0', '--traffic_child', '1', '--profile', '0',
              '--per_gpu_batch', str(args.per_gpu_batch), '--img_h', str(args.img_h), '--img_w', str(args.img_w),

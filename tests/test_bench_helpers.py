@@ -70,6 +70,11 @@ def test_measure_traffic_reports_a_missing_profiler_instead_of_raising(bench, mo
     monkeypatch.setattr(os.path, 'exists', lambda p: False if 'rocprofv3' in str(p) else real_exists(p))
     out = bench.measure_traffic(type('A', (), {})())
     assert out == {'error': 'rocprofv3 not found'}
+    # ... and never starts a profiler inside a profiler
+    monkeypatch.setattr(os.path, 'exists', real_exists)
+    monkeypatch.setattr(shutil, 'which', lambda name: sys.executable)
+    monkeypatch.setenv('ROCPROFILER_SOMETHING', '1')
+    assert 'running under a profiler' in bench.measure_traffic(type('A', (), {})())['error']
 
 
 def test_reference_schedule_result_is_read_from_the_committed_log(bench):
