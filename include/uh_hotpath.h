@@ -26,16 +26,13 @@
  *        <- solve_DLT + transform + l1 loss and their backward as one hipGraph
  *   uh_warp_patch_l1_fwdbwd
  *        <- the composition of the four above restricted to the P x P loss patch
- *   uh_prefetch / uh_prefetch_async / uh_prefetch_join   (ABI version 5)
- *        <- nothing in the reference: an opt-in scheduling hint for the 256 MB Infinity Cache (DESIGN.md 3.1 "Round 4")
  *
  * Conventions
  *   - every `const float*` / `float*` / `const int*` below is a DEVICE pointer owned by the caller,
  *     contiguous, row-major, 4-byte aligned, unless the comment says HOST.  Images are NHWC.
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
  *     stream); nothing synchronises, allocates or frees; no global mutable state other than the
- *     optional profiler below, the zeroed-pair counter (uh_dlt_zeroed_pairs: the one call that DOES
- *     synchronise) and the side stream uh_prefetch_async creates on first use; entry points are thread-safe.
+ *     optional profiler below; entry points are thread-safe.
  *   - return value: 0 = ok; >0 = a hipError_t raised by the launch; <0 = argument error (UH_E_*).
  *   - arithmetic: IEEE f32, FP contraction OFF on the forward paths so that results are op-for-op
  *     those of the un-fused TF-CPU graph (see DESIGN.md "Numerics").
