@@ -133,3 +133,13 @@ def test_regressor_flops_match_the_survey(bench):
     """2.52 GFLOP forward per pair at P = 128 (block1 1.246, block2 0.604, block3 0.453, block4 0.151, fc 0.067)."""
     assert abs(bench.regressor_flops(128) / 1e9 - 2.52) < 0.005
     assert bench.regressor_flops(64) < bench.regressor_flops(128) / 3.9
+
+
+def test_committed_traffic_file_was_measured_on_the_current_kernel_sources():
+    """The fallback for roofline.traffic must not go stale silently: profiles/traffic_r04.json stores build._fingerprint() of
+    the sources it was measured on.  Editing csrc/ or include/ (even a comment: the header is part of the build stamp) makes
+    this fail until `tools/gpu_session.sh rNN traffic` has been re-run and its file committed -- or the name of the newest
+    file in bench.TRAFFIC_FILES bumped."""
+    from unsuperviseddeephomographyral2018_amd import build
+    tr = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r04.json')))
+    assert tr['_fingerprint'] == build._fingerprint()
