@@ -55,6 +55,9 @@ def parse():
     ap.add_argument('--prefetch_frame', type=int, default=0,
                     help='1: I is read into the Infinity Cache on a side stream under the regressor\'s tail, the warp then samples a '
                          'warm frame (faster kernel, slower step: see roofline.with_frame_prefetch); 0: the trainer default')
+    ap.add_argument('--tunable_gemm', type=int, default=0,
+                    help='1: PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of each GEMM shape '
+                         'benchmarks the rocBLAS / hipBLASLt candidates, like MIOpen find does for the convs')
     ap.add_argument('--graph_tail', type=int, default=0, help='1: DLT->warp->loss and backward as one hipGraph launch')
     ap.add_argument('--step_graph', type=int, default=0, help='1: whole training step as one hipGraph replay (implies --profile 0)')
     ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object); 1: time the warp kernels; 2: time every library kernel')
@@ -373,7 +376,7 @@ def measure_traffic(args, timeout_s=180):
              '--per_gpu_batch', str(args.per_gpu_batch), '--img_h', str(args.img_h), '--img_w', str(args.img_w),
              '--patch_size', str(args.patch_size), '--rho', str(args.rho), '--loss_type', args.loss_type,
              '--fused_patch', str(args.fused_patch), '--mid_training_theta', str(args.mid_training_theta),
-             '--prefetch_frame', str(args.prefetch_frame)]
+             '--prefetch_frame', str(args.prefetch_frame), '--tunable_gemm', '0']
     vals = {}
     t0 = time.perf_counter()
     with tempfile.TemporaryDirectory(dir='/tmp') as td:
@@ -481,6 +484,7 @@ def main():
     # counters: immediate mode there, so that no find-mode trial kernel is profiled.)
     torch.backends.cudnn.benchmark = not args.traffic_child
     uh_dist.skip_naive_conv_in_find()                       # ... without benchmarking MIOpen's reference (naive) solvers
+    tuned_gemms = uh_dist.tune_gemms() if args.tunable_gemm else False
     torch.manual_seed(1234)
 
     if args.only_points:
@@ -705,6 +709,7 @@ def main():
                                          'frame; its HBM read traffic moves to the prefetch kernel (roofline.kernels.prefetch, '
                                          'traffic_prefetch_kernel)')
     out['config']['warmup_seconds'] = round(warmup_s, 1)
+    out['config']['tunable_gemm'] = bool(tuned_gemms)
     out['config']['miopen_find'] = ('cudnn.benchmark = True; reference solvers excluded from the trials '
                                     '(MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD/BWD/WRW=%s)' % os.environ.get('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'))
     if other_law is not None and isinstance(out.get('roofline'), dict):

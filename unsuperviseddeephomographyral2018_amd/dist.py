@@ -73,6 +73,25 @@ def skip_naive_conv_in_find():
         os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_' + k, '0')
 
 
+def tune_gemms(max_ms_per_solution=15, max_iterations=20, filename=None):
+    """PyTorch's TunableOp for the regressor's fully connected GEMMs -- what cudnn.benchmark / MIOpen find is for its convs.
+    fc1 is a skinny GEMM (batch x 32768 x 1024: 134 MB of weights for 64 rows); the library heuristic's pick runs the forward
+    in 142 us where the weights could stream in ~25 (profiles/r04_step_breakdown.txt).  With TunableOp on, the first call of
+    each GEMM shape benchmarks the rocBLAS / hipBLASLt candidates and keeps the fastest; results are cached in `filename`
+    (default /tmp/uh_tunableop_<device>.csv, validated against the library versions), so later processes on the same host
+    skip the search.  Returns True when TunableOp was switched on."""
+    try:
+        import torch.cuda.tunable as tun
+        tun.set_filename(filename or '/tmp/uh_tunableop.csv', insert_device_ordinal=True)
+        tun.set_max_tuning_duration(int(max_ms_per_solution))
+        tun.set_max_tuning_iterations(int(max_iterations))
+        tun.enable(True)
+        tun.tuning_enable(True)
+        return True
+    except Exception:                                        # noqa: BLE001 -- an optimisation, never a requirement
+        return False
+
+
 def seed_tower_rng(seed, rank):
     """Every tower draws its OWN dropout masks: the reference builds one slim.dropout op per tower
     (homography_model.py:120-121,128, one model per tower at homography_CNN_synthetic.py:229-233), so the masks of two
