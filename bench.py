@@ -55,9 +55,9 @@ def parse():
     ap.add_argument('--prefetch_frame', type=int, default=0,
                     help='1: I is read into the Infinity Cache on a side stream under the regressor\'s tail, the warp then samples a '
                          'warm frame (faster kernel, slower step: see roofline.with_frame_prefetch); 0: the trainer default')
-    ap.add_argument('--tunable_gemm', type=int, default=0,
-                    help='1: PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of each GEMM shape '
-                         'benchmarks the rocBLAS / hipBLASLt candidates, like MIOpen find does for the convs')
+    ap.add_argument('--tunable_gemm', type=int, default=1,
+                    help='1 (the trainer default): PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of '
+                         'each GEMM shape benchmarks the rocBLAS / hipBLASLt candidates, like MIOpen find does for the convs; 0: off')
     ap.add_argument('--graph_tail', type=int, default=0, help='1: DLT->warp->loss and backward as one hipGraph launch')
     ap.add_argument('--step_graph', type=int, default=0, help='1: whole training step as one hipGraph replay (implies --profile 0)')
     ap.add_argument('--profile', type=int, default=1, help='0: no per-kernel events in the timed region (no roofline object); 1: time the warp kernels; 2: time every library kernel')
@@ -709,7 +709,8 @@ def main():
                                          'frame; its HBM read traffic moves to the prefetch kernel (roofline.kernels.prefetch, '
                                          'traffic_prefetch_kernel)')
     out['config']['warmup_seconds'] = round(warmup_s, 1)
-    out['config']['tunable_gemm'] = bool(tuned_gemms)
+    out['config']['tunable_gemm'] = ('on: torch.cuda.tunable picked the fully connected GEMMs (fc1 forward 142 -> 55 us; --tunable_gemm 0 = rounds 1-3)'
+                                     if tuned_gemms else 'off')
     out['config']['miopen_find'] = ('cudnn.benchmark = True; reference solvers excluded from the trials '
                                     '(MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD/BWD/WRW=%s)' % os.environ.get('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'))
     if other_law is not None and isinstance(out.get('roofline'), dict):

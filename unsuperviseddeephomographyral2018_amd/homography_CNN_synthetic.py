@@ -83,6 +83,10 @@ def build_parser():
                    help='read I into the 256 MB Infinity Cache on a side stream while the regressor\'s last small kernels run, so '
                         'that the warp samples a warm frame (ops.prefetch_frame / uh_prefetch_async); same bits.  Off by default: '
                         'the warp forward gets 9 us faster, the step 60 - 90 us slower (a second active HW queue)')
+    p.add_argument('--tunable_gemm', type=str2bool, default='True',
+                   help='PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of each GEMM shape benchmarks '
+                        'the rocBLAS / hipBLASLt candidates, as cudnn.benchmark does for the convs (~3 s once per host; fc1 forward '
+                        '142 -> 55 us, the step -1.5 %)')
     p.add_argument('--step_graph', type=str2bool, default='False',
                    help='capture the whole training step (convs, hot path, Adam) into one hipGraph and replay it')
     p.add_argument('--graph_tail', type=str2bool, default='False',
@@ -339,6 +343,8 @@ def train(args):
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = True                   # MIOpen find: shapes are static
     uh_dist.skip_naive_conv_in_find()
+    if getattr(args, 'tunable_gemm', True):
+        uh_dist.tune_gemms()                                # ... and the same kind of search for the fully connected GEMMs
     torch.manual_seed(args.seed)
     step_fn = TrainStep(args, device, world)
     ckpt_dir, ckpt = _ckpt_path(args)
