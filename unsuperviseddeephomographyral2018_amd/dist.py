@@ -78,11 +78,13 @@ def tune_gemms(max_ms_per_solution=15, max_iterations=20, filename=None):
     fc1 is a skinny GEMM (batch x 32768 x 1024: 134 MB of weights for 64 rows); the library heuristic's pick runs the forward
     in 142 us where the weights could stream in ~25 (profiles/r04_step_breakdown.txt).  With TunableOp on, the first call of
     each GEMM shape benchmarks the rocBLAS / hipBLASLt candidates and keeps the fastest; results are cached in `filename`
-    (default /tmp/uh_tunableop_<device>.csv, validated against the library versions), so later processes on the same host
+    (default /tmp/uh_tunableop[_r<local rank>_]<device>.csv, validated against the library versions), so later processes on the same host
     skip the search.  Returns True when TunableOp was switched on."""
     try:
         import torch.cuda.tunable as tun
-        tun.set_filename(filename or '/tmp/uh_tunableop.csv', insert_device_ordinal=True)
+        # one results file per (local rank, device): ranks that share a GPU (gloo dry runs) must not write the same file at exit
+        lr = os.environ.get('LOCAL_RANK')
+        tun.set_filename(filename or ('/tmp/uh_tunableop%s.csv' % ('_r' + lr + '_' if lr is not None else '')), insert_device_ordinal=True)
         tun.set_max_tuning_duration(int(max_ms_per_solution))
         tun.set_max_tuning_iterations(int(max_iterations))
         tun.enable(True)
