@@ -53,8 +53,9 @@ def parse():
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
     ap.add_argument('--prefetch_frame', type=int, default=0,
-                    help='1: I is read into the Infinity Cache on a side stream under the regressor\'s tail, the warp then samples a '
-                         'warm frame (faster kernel, slower step: see roofline.with_frame_prefetch); 0: the trainer default')
+                    help='Infinity-Cache prefetch of I before the warp samples it: 0 off (the trainer default); 1 on a side stream forked '
+                         'after fc1; 2 by rider blocks of the DLT-solve launch.  The default run measures both after the timed region '
+                         '(roofline.with_frame_prefetch)')
     ap.add_argument('--tunable_gemm', type=int, default=1,
                     help='1 (the trainer default): PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of '
                          'each GEMM shape benchmarks the rocBLAS / hipBLASLt candidates, like MIOpen find does for the convs; 0: off')
@@ -502,7 +503,7 @@ def main():
         '--img_h', str(args.img_h), '--img_w', str(args.img_w), '--patch_size', str(args.patch_size),
         '--rho', str(args.rho), '--fused_patch', 'True' if args.fused_patch else 'False',
         '--graph_tail', 'True' if args.graph_tail else 'False', '--step_graph', 'True' if args.step_graph else 'False',
-        '--prefetch_frame', 'True' if args.prefetch_frame else 'False'])
+        '--prefetch_frame', {0: 'off', 1: 'side', 2: 'dlt'}.get(args.prefetch_frame, 'off')])
     if args.step_graph:
         args.profile = 0                                    # per-kernel events cannot be inserted into a replayed graph
     step_fn = TrainStep(targs, device, world)
@@ -588,7 +589,8 @@ def main():
         except Exception as e:                              # noqa: BLE001 -- an extra, must not lose the headline
             temps = {'error': '%s: %s' % (type(e).__name__, e)}
     # The measured remedy for the cold frame, and why it is not the default (round 4): a few untimed steps with the frame
-    # prefetched on the library's side stream -- kernel durations by dispatch events, then step time with and without, events off.
+    # prefetched -- by rider blocks of the DLT launch, and on the library's side stream -- kernel durations by dispatch events, then
+    # step time with and without, events off.
     with_pf = None
     if args.profile and world == 1 and not args.step_graph and not args.fused_patch and not args.traffic_child and not args.prefetch_frame:
         try:
@@ -599,26 +601,37 @@ def main():
                     step_fn(batch)
                 torch.cuda.synchronize(device)
                 return (time.perf_counter() - t_a) / n * 1e3
-            step_fn.args.prefetch_frame = True
+            with_pf = {}
+            alg_fwd = 2 * B * args.img_h * args.img_w * 3 * 4
+            for mode in ('dlt', 'side'):
+                step_fn.args.prefetch_frame = mode
+                steps_ms(3)
+                _lib.profile_enable(True, only=('warp_forward', 'prefetch', 'dlt_forward'))
+                steps_ms(10)
+                p3 = _lib.profile_read()
+                _lib.profile_enable(False)
+                ms_on = steps_ms(20)
+                us3 = p3['warp_forward'][0] / max(p3['warp_forward'][1], 1) * 1e3
+                with_pf[mode] = {'warp_forward_avg_us': round(us3, 2), 'frac': round(alg_fwd / (us3 * 1e-6) / HBM_PEAK, 4),
+                                 'dlt_forward_avg_us': round(p3['dlt_forward'][0] / max(p3['dlt_forward'][1], 1) * 1e3, 2),
+                                 'side_stream_prefetch_kernel_avg_us': (round(p3['prefetch'][0] / p3['prefetch'][1] * 1e3, 2)
+                                                                        if p3['prefetch'][1] else None),
+                                 'ms_per_step': round(ms_on, 3)}
+            step_fn.args.prefetch_frame = 'off'
             steps_ms(3)
-            _lib.profile_enable(True, only=('warp_forward', 'prefetch'))
+            _lib.profile_enable(True, only=('warp_forward', 'dlt_forward'))
             steps_ms(10)
-            p3 = _lib.profile_read()
+            p4 = _lib.profile_read()
             _lib.profile_enable(False)
-            ms_on = steps_ms(20)
-            step_fn.args.prefetch_frame = False
-            steps_ms(3)
-            ms_off = steps_ms(20)
-            us3 = p3['warp_forward'][0] / max(p3['warp_forward'][1], 1) * 1e3
-            with_pf = {'warp_forward_avg_us': round(us3, 2),
-                       'frac': round(2 * B * args.img_h * args.img_w * 3 * 4 / (us3 * 1e-6) / HBM_PEAK, 4),
-                       'prefetch_kernel_avg_us': round(p3['prefetch'][0] / max(p3['prefetch'][1], 1) * 1e3, 2),
-                       'ms_per_step_with_prefetch': round(ms_on, 3), 'ms_per_step_without': round(ms_off, 3),
-                       'note': '--prefetch_frame True (ops.prefetch_frame: uh_prefetch_async reads I into the Infinity Cache on a side stream '
-                               'after fc1; the warp samples a warm frame).  NOT the default: the second active HW queue costs the step more '
-                               'than the warm frame saves.  10 + 20 + 20 untimed steps after the timed region, same batch, same theta law'}
+            with_pf['off'] = {'warp_forward_avg_us': round(p4['warp_forward'][0] / max(p4['warp_forward'][1], 1) * 1e3, 2),
+                              'dlt_forward_avg_us': round(p4['dlt_forward'][0] / max(p4['dlt_forward'][1], 1) * 1e3, 2),
+                              'ms_per_step': round(steps_ms(20), 3)}
+            with_pf['note'] = ("--prefetch_frame dlt: rider blocks of the DLT-solve launch read I into the Infinity Cache (uh_dlt_forward_prefetch; "
+                               "the solve is latency-bound, no second stream); --prefetch_frame side: uh_prefetch_async on a side stream forked "
+                               "after fc1.  The warp then samples a warm frame.  Neither is the trainer default: see ms_per_step against 'off'.  "
+                               "3 + 10 + 20 untimed steps per mode after the timed region, same batch, same theta law")
         except Exception as e:                              # noqa: BLE001 -- an extra, must not lose the headline
-            step_fn.args.prefetch_frame = False
+            step_fn.args.prefetch_frame = 'off'
             with_pf = {'error': '%s: %s' % (type(e).__name__, e)}
     loss_val = float(model.loss.detach())
 
@@ -702,12 +715,11 @@ def main():
                                 'note': 'whole train step (3 x forward FLOPs of the VGG regressor x global batch) / ms_per_step against the f32-input '
                                         'MFMA peak per GPU (v_mfma_f32_32x32x2_f32 = the f32 vector rate; gfx950 has no xf32 / TF32): the conv '
                                         'stack is stock MIOpen by north_star, the hand-written hot path is 1.5 % of the step'}
-    out['config']['frame_prefetch'] = bool(args.prefetch_frame)
+    out['config']['frame_prefetch'] = {0: 'off', 1: 'side', 2: 'dlt'}.get(args.prefetch_frame, 'off')
     if args.prefetch_frame and isinstance(out.get('roofline'), dict):
-        out['roofline']['input_state'] = ('NOT the trainer default: I is read into the 256 MB Infinity Cache by uh_prefetch_async on a side '
-                                         'stream while fc2 and the DLT solve run (--prefetch_frame 1): the in-step forward samples a WARM '
-                                         'frame; its HBM read traffic moves to the prefetch kernel (roofline.kernels.prefetch, '
-                                         'traffic_prefetch_kernel)')
+        out['roofline']['input_state'] = ('NOT the trainer default: I is read into the 256 MB Infinity Cache before the warp samples it (--prefetch_frame '
+                                         '1: uh_prefetch_async on a side stream while fc2 and the DLT solve run; 2: rider blocks of the DLT-solve '
+                                         'launch): the in-step forward samples a WARM frame; its HBM read traffic moves to the prefetching launch')
     out['config']['warmup_seconds'] = round(warmup_s, 1)
     out['config']['tunable_gemm'] = ('on: torch.cuda.tunable picked the fully connected GEMMs (fc1 forward 142 -> 55 us; --tunable_gemm 0 = rounds 1-3)'
                                      if tuned_gemms else 'off')

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define UH_ABI_VERSION 5
+#define UH_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define UH_API __attribute__((visibility("default")))
@@ -86,6 +86,13 @@ UH_API int uh_dlt_forward(const float* pts1, const float* h4p, float* H, float* 
 
 /* Gradient w.r.t. h4p.  Exactly one of dH / dtheta must be non-NULL: with dtheta the kernel first
  * folds dH = Minv^T dtheta M^T.  H is the forward output.                                        */
+/* The same launch with RIDER blocks that read `prefetch_bytes` bytes at `prefetch_ptr` once and discard them (ABI 6): the solve is
+ * latency-bound and leaves HBM idle, the frame the warp samples next ends up in the 256 MB Infinity Cache -- uh_warp_forward on
+ * it then costs 19 us instead of 27 (batch 64, 240x320).  No reference counterpart; prefetch_ptr NULL = uh_dlt_forward.        */
+UH_API int uh_dlt_forward_prefetch(const float* pts1, const float* h4p, float* H, float* theta,
+                            const float* M_host, const float* Minv_host, int B, unsigned flags,
+                            const void* prefetch_ptr, size_t prefetch_bytes, uh_stream_t stream);
+
 UH_API int uh_dlt_backward(const float* pts1, const float* h4p, const float* H,
                     const float* dH, const float* dtheta,
                     const float* M_host, const float* Minv_host,

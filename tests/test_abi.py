@@ -81,6 +81,8 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert lib.uh_kernel_name(2) == b'warp_forward'
     # uh_prefetch (round 4): NULL refused; a range that holds no whole 16-byte chunk is a no-op that launches nothing
     assert lib.uh_prefetch(None, 4096, None) == -1 and lib.uh_prefetch_async(None, 4096, None) == -1
+    assert lib.uh_dlt_forward_prefetch(None, one, one, None, None, None, 4, 0, one, 4096, None) == -1
+    assert lib.uh_dlt_forward_prefetch(one, one, one, None, None, None, 0, 0, one, 4096, None) == -2
     assert lib.uh_prefetch(one, 0, None) == 0 and lib.uh_prefetch(C.c_void_p(1), 30, None) == 0
     assert lib.uh_kernel_name(17) == b'prefetch' and lib.uh_kernel_name(18) == b'?'
     # entry points added after the first slice

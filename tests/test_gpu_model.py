@@ -584,18 +584,18 @@ def test_frame_prefetch_is_a_hint_same_bits_and_untouched_memory(pkg, dev):
     torch.backends.cudnn.deterministic = True
     outs = {}
     try:
-        for tag, pf, at in (('off', False, 'fc2'), ('after_fc1', True, 'fc2'), ('before_fc1', True, 'fc1')):
+        for tag, pf, at in (('off', False, 'fc2'), ('after_fc1', True, 'fc2'), ('before_fc1', True, 'fc1'), ('dlt_riders', 'dlt', 'fc2')):
             os.environ['UH_PREFETCH_AT'] = at
             m = hm.HomographyModel(params(hm, 'train', B, P, W, H, 'l1_loss'), *synthetic.model_args(batch), net=net,
                                    prefetch_frame=pf)
-            assert m.prefetch_frame == pf
+            assert m.prefetch_mode == {False: 'off', True: 'side', 'dlt': 'dlt'}[pf] and m.prefetch_frame == (pf is True)
             (g,) = torch.autograd.grad(m.loss, m.pred_h4p)
             outs[tag] = [t.detach().clone() for t in (m.pred_h4p, m.H_mat, m.pred_I2, m.l1_loss, m.rec_loss, m.ssim_loss, g)]
     finally:
         os.environ.pop('UH_PREFETCH_AT', None)
         torch.backends.cudnn.deterministic = keep_det
     torch.cuda.synchronize(dev)
-    for tag in ('after_fc1', 'before_fc1'):
+    for tag in ('after_fc1', 'before_fc1', 'dlt_riders'):
         for a, b in zip(outs['off'], outs[tag]):
             assert torch.equal(a, b), tag
     # the C entry point on ranges that are neither 16-byte aligned nor a multiple of 16 bytes long
@@ -606,6 +606,12 @@ def test_frame_prefetch_is_a_hint_same_bits_and_untouched_memory(pkg, dev):
         _lib.check(lib.uh_prefetch(C.c_void_p(buf.data_ptr() + off), nbytes, st), 'uh_prefetch')
     ops.prefetch_frame(buf)
     ops.join_prefetch(dev)
+    # ... and the rider-block form: the DLT solve with a prefetch range returns the same H / theta bits, touches nothing
+    pts1, h4p = batch['pts1'], torch.randn(B, 8, device=dev) * 5
+    Ha, ta = ops.solve_dlt(pts1, h4p, W, H)
+    for rng in (buf, buf[1:], buf[:7], batch['I_aug']):
+        Hb, tb = ops.solve_dlt(pts1, h4p, W, H, prefetch=rng if rng.is_contiguous() else None)
+        assert torch.equal(Ha, Hb) and torch.equal(ta, tb)
     torch.cuda.synchronize(dev)
     assert torch.equal(buf, ref)
     with pytest.raises(_lib.UHError):

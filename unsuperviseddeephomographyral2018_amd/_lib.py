@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UH_LIB_PATH lets a developer A/B a differently-built copy of the SAME library (tools/); it is not a fallback.
 LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hotpath.so')
 
-UH_ABI_VERSION = 5
+UH_ABI_VERSION = 6
 UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
 UH_DLT_ZERO_NONFINITE_GRAD = 8
@@ -26,6 +26,7 @@ SIGNATURES = {
     'uh_abi_version': (_i, []),
     'uh_error_string': (C.c_char_p, [_i]),
     'uh_dlt_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _u, _p]),
+    'uh_dlt_forward_prefetch': (_i, [_p, _p, _p, _p, _p, _p, _i, _u, _p, _z, _p]),
     'uh_dlt_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _u, _p]),
     'uh_dlt_zeroed_pairs': (_i, [_p, _i]),
     'uh_warp_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -79,10 +79,10 @@ def build_parser():
                    help='train mode: a pair whose d loss / d pred_h4p is NaN / Inf (degenerate predicted corners) contributes '
                         'no gradient instead of poisoning every variable (UH_DLT_ZERO_NONFINITE_GRAD).  False = the '
                         'reference\'s behaviour: tf.matrix_solve + autodiff pass the NaN on.  The log line counts the pairs.')
-    p.add_argument('--prefetch_frame', type=str2bool, default='False',
-                   help='read I into the 256 MB Infinity Cache on a side stream while the regressor\'s last small kernels run, so '
-                        'that the warp samples a warm frame (ops.prefetch_frame / uh_prefetch_async); same bits.  Off by default: '
-                        'the warp forward gets 9 us faster, the step 60 - 90 us slower (a second active HW queue)')
+    p.add_argument('--prefetch_frame', type=str, default='off',
+                   help="read I into the 256 MB Infinity Cache before the warp samples it (a scheduling hint, same bits): 'off' (default), "
+                        "'dlt' = rider blocks of the DLT-solve launch do the read, 'side' (or True) = a side stream forked after fc1 "
+                        "(warp forward 9 us faster, step 60 - 90 us slower: a second active HW queue)")
     p.add_argument('--tunable_gemm', type=str2bool, default='True',
                    help='PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of each GEMM shape benchmarks '
                         'the rocBLAS / hipBLASLt candidates, as cudnn.benchmark does for the convs (~3 s once per host; fc1 forward '

@@ -128,6 +128,18 @@ def reset_variables():
     _VARIABLE_SCOPE.clear()
 
 
+def prefetch_mode(v):
+    """'off' | 'dlt' | 'side' from a flag value (bool, '0' / '1' / '2', 'True' / 'False', or the names themselves)."""
+    if isinstance(v, bool):
+        return 'side' if v else 'off'
+    s = str(v).strip().lower()
+    if s in ('dlt', '2'):
+        return 'dlt'
+    if s in ('side', 'true', '1'):
+        return 'side'
+    return 'off'
+
+
 class HomographyModel(object):
     def __init__(self, args, I1, I2, I1_aug, I2_aug, I_aug, I_prime_aug, h4p, gt, patch_indices,
                  reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False, graph_tail=False,
@@ -152,14 +164,18 @@ class HomographyModel(object):
         self.fused_patch = fused_patch
         self.solve_f64 = solve_f64
         self.h4p_offset = h4p_offset        # [B,8] added to the regressor's output (bench / test hook; None = off)
-        # Infinity-Cache prefetch of I under the regressor's tail (ops.prefetch_frame): a scheduling hint, bits unchanged.
-        # OFF by default: it takes the in-step warp forward from 27.5 to 18.8 us (0.54 -> 0.79 of the roofline), but a second
-        # active HW queue costs the step 60 - 90 us -- ten times what the warm frame saves (DESIGN.md 3.1 "Round 4",
-        # profiles/r04_prefetch_ab_*.jsonl).  None = UH_PREFETCH_FRAME (default 0); UH_PREFETCH_AT=fc1 forks before fc1
+        # Infinity-Cache prefetch of I before the warp samples it -- a scheduling hint, bits unchanged.  Three modes:
+        #   'off'  (default)
+        #   'dlt'  rider blocks of the DLT-solve launch read I (ops.solve_dlt(prefetch=I) -> uh_dlt_forward_prefetch): no
+        #          second stream; the solve is latency-bound and leaves HBM idle
+        #   'side' (or True) a side stream forked after fc1 (ops.prefetch_frame): the warp forward drops from 27.5 to 18.8 us
+        #          but a second active HW queue costs the step 60 - 90 us (DESIGN.md 3.1 "Round 4", profiles/r04_prefetch_ab_*)
+        # None = UH_PREFETCH_FRAME ('0' / 'off', '1' / 'side', 'dlt'); UH_PREFETCH_AT=fc1 forks the side stream before fc1
         import os
         if prefetch_frame is None:
-            prefetch_frame = os.environ.get('UH_PREFETCH_FRAME', '0') == '1'
-        self.prefetch_frame = bool(prefetch_frame) and I_aug.is_cuda
+            prefetch_frame = os.environ.get('UH_PREFETCH_FRAME', 'off')
+        self.prefetch_mode = prefetch_mode(prefetch_frame) if I_aug.is_cuda else 'off'
+        self.prefetch_frame = self.prefetch_mode == 'side'
         self._prefetch_before_fc1 = os.environ.get('UH_PREFETCH_AT', 'fc2') == 'fc1'
         # A pair whose predicted corners are degenerate (collinear p2 -> singular 8x8 system -> theta = NaN) must not turn
         # every variable into NaN: in training its d loss / d pred_h4p is zeroed (UH_DLT_ZERO_NONFINITE_GRAD).  The reference
@@ -225,7 +241,8 @@ class HomographyModel(object):
         with torch.set_grad_enabled(self._hot_grad):
             self.H_mat, self._theta = ops.solve_dlt(self.pts_1, self.pred_h4p, self.params.img_w,
                                                     self.params.img_h, solve_f64=self.solve_f64,
-                                                    zero_nonfinite_grad=self.zero_nonfinite_grad)
+                                                    zero_nonfinite_grad=self.zero_nonfinite_grad,
+                                                    prefetch=self.I if self.prefetch_mode == 'dlt' else None)
 
     # ---- homography_model.py:252-269 ----------------------------------------------------------------
     def transform(self):

@@ -81,7 +81,7 @@ class _DLTSolve(torch.autograd.Function):
     """pts1, h4p -> (H [B,3,3], theta [B,3,3] or None).  Gradient flows to h4p only (pts1 is data)."""
 
     @staticmethod
-    def forward(ctx, pts1, h4p, M, Minv, flags):
+    def forward(ctx, pts1, h4p, M, Minv, flags, prefetch=None):
         lib = _lib.load()
         pts1 = _f32(pts1, 'pts1').reshape(-1, 8)
         h4p = _f32(h4p, 'h4p').reshape(-1, 8)
@@ -94,8 +94,14 @@ class _DLTSolve(torch.autograd.Function):
         if M is not None:
             ctx.M_keep, Mh = _host9(M)
             ctx.Mi_keep, Mih = _host9(Minv)
-        _lib.check(lib.uh_dlt_forward(_ptr(pts1), _ptr(h4p), _ptr(H), _ptr(theta), Mh, Mih, B, flags, _stream()),
-                   'uh_dlt_forward')
+        if prefetch is not None and prefetch.is_cuda and prefetch.is_contiguous():
+            # rider blocks of the same launch read `prefetch` once (Infinity-Cache prefetch of the frame the warp samples next)
+            _lib.check(lib.uh_dlt_forward_prefetch(_ptr(pts1), _ptr(h4p), _ptr(H), _ptr(theta), Mh, Mih, B, flags,
+                                                   C.c_void_p(prefetch.data_ptr()), prefetch.numel() * prefetch.element_size(),
+                                                   _stream()), 'uh_dlt_forward_prefetch')
+        else:
+            _lib.check(lib.uh_dlt_forward(_ptr(pts1), _ptr(h4p), _ptr(H), _ptr(theta), Mh, Mih, B, flags, _stream()),
+                       'uh_dlt_forward')
         ctx.save_for_backward(pts1, h4p, H)
         ctx.set_materialize_grads(False)       # an unused output arrives as None, not as zeros
         ctx.flags = flags
@@ -130,18 +136,21 @@ class _DLTSolve(torch.autograd.Function):
             run((dH + Mit.t() @ dtheta @ Mt.t()).contiguous(), None)
         else:
             run(_f32(dH, 'dH'), None)
-        return None, dh4p, None, None, None
+        return None, dh4p, None, None, None, None
 
 
-def solve_dlt(pts1, h4p, img_w=None, img_h=None, solve_f64=False, zero_nonfinite_grad=False):
-    """Tensor-DLT.  Returns H [B,3,3]; with img_w/img_h also theta = M^-1 H M (transform() :254)."""
+def solve_dlt(pts1, h4p, img_w=None, img_h=None, solve_f64=False, zero_nonfinite_grad=False, prefetch=None):
+    """Tensor-DLT.  Returns H [B,3,3]; with img_w/img_h also theta = M^-1 H M (transform() :254).
+    `prefetch` (optional device tensor, e.g. the frame the warp will sample): read once by rider blocks of the same launch."""
     flags = _lib.UH_DLT_SOLVE_F64 if solve_f64 else _lib.UH_DLT_SOLVE_F32
     if zero_nonfinite_grad:          # a pair with degenerate predicted corners contributes no gradient (see the header)
         flags |= _lib.UH_DLT_ZERO_NONFINITE_GRAD
+    if prefetch is not None:
+        prefetch = prefetch.detach()
     if img_w is None:
-        return _DLTSolve.apply(pts1, h4p, None, None, flags)
+        return _DLTSolve.apply(pts1, h4p, None, None, flags, prefetch)
     M, Minv = m_and_minv(img_w, img_h)
-    return _DLTSolve.apply(pts1, h4p, M, Minv, flags)
+    return _DLTSolve.apply(pts1, h4p, M, Minv, flags, prefetch)
 
 
 # ------------------------------------------------------------------------------------------------
