@@ -19,6 +19,10 @@
 #   bench8[:N]      python bench.py --gpus N (default 8) on ONE GPU over gloo, find pass staggered and not, cold MIOpen db each
 #   cold            tools/cold_forward.py (in-step forward: cold / warm x batch sweep x theta law)
 #   train_ref       tools/train_reference_schedule.sh (150 000 steps at the reference's schedule + test loop)
+#   dpsmooth / dpnoise   the two data-dependent DP tests on smooth textures (pinned / default solvers) / on the default solvers
+#   coldv:V1,V2     cold-forward A/B/A/B of the shipped library against variants (batches 64, 128)
+#   power:LIBS:K    tools/power_ab.py: duration + socket power + energy per launch of kernel K (fwd | bwd) per library build
+#   prefetch_ab     the side-stream frame prefetch in the train step: off / join / fire-and-forget / profiler events with the fence
 #   trace:V         per-wave phase trace with the -DUH_WARP_TRACE variant V (tools/trace_waves.py)
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 TAG=$1; shift
