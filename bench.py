@@ -52,10 +52,6 @@ def parse():
     ap.add_argument('--rho', type=int, default=45)
     ap.add_argument('--loss_type', default='l1_loss')
     ap.add_argument('--fused_patch', type=int, default=0, help='1: fused patch kernel instead of the full-frame warp')
-    ap.add_argument('--prefetch_frame', type=int, default=0,
-                    help='Infinity-Cache prefetch of I before the warp samples it: 0 off (the trainer default); 1 on a side stream forked '
-                         'after fc1; 2 by rider blocks of the DLT-solve launch.  The default run measures both after the timed region '
-                         '(roofline.with_frame_prefetch)')
     ap.add_argument('--tunable_gemm', type=int, default=1,
                     help='1 (the trainer default): PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of '
                          'each GEMM shape benchmarks the rocBLAS / hipBLASLt candidates, like MIOpen find does for the convs; 0: off')
@@ -329,7 +325,7 @@ def library_fingerprint():
         return uh_build._fingerprint()
 
 
-TRAFFIC_FILES = ('traffic_r04.json', 'traffic_r03.json', 'traffic_r02.json', 'traffic_r01.json')
+TRAFFIC_FILES = ('traffic_r05.json', 'traffic_r04.json', 'traffic_r03.json', 'traffic_r02.json', 'traffic_r01.json')
 
 
 def committed_traffic(key):
@@ -376,8 +372,7 @@ def measure_traffic(args, timeout_s=180):
              '--config4', '1' if args.config4 else '0', '--quality', '0', '--traffic', '0', '--traffic_child', '1', '--profile', '0',
              '--per_gpu_batch', str(args.per_gpu_batch), '--img_h', str(args.img_h), '--img_w', str(args.img_w),
              '--patch_size', str(args.patch_size), '--rho', str(args.rho), '--loss_type', args.loss_type,
-             '--fused_patch', str(args.fused_patch), '--mid_training_theta', str(args.mid_training_theta),
-             '--prefetch_frame', str(args.prefetch_frame), '--tunable_gemm', '0']
+             '--fused_patch', str(args.fused_patch), '--mid_training_theta', str(args.mid_training_theta), '--tunable_gemm', '0']
     vals = {}
     t0 = time.perf_counter()
     with tempfile.TemporaryDirectory(dir='/tmp') as td:
@@ -400,7 +395,7 @@ def measure_traffic(args, timeout_s=180):
             for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
                 for r in csv.DictReader(open(f)):
                     k = r.get('Kernel_Name', '')
-                    if ('uh::warp_' not in k and 'uh::prefetch_kernel' not in k) or r.get('Counter_Name') != counter:
+                    if 'uh::warp_' not in k or r.get('Counter_Name') != counter:
                         continue
                     name = k.replace('void ', '').split('(')[0].replace('uh::', '')
                     wg = int(float(r.get('Workgroup_Size', 256) or 256))
@@ -502,8 +497,7 @@ def main():
         '--mode', 'train', '--loss_type', args.loss_type, '--batch_size', str(B * world),
         '--img_h', str(args.img_h), '--img_w', str(args.img_w), '--patch_size', str(args.patch_size),
         '--rho', str(args.rho), '--fused_patch', 'True' if args.fused_patch else 'False',
-        '--graph_tail', 'True' if args.graph_tail else 'False', '--step_graph', 'True' if args.step_graph else 'False',
-        '--prefetch_frame', {0: 'off', 1: 'side', 2: 'dlt'}.get(args.prefetch_frame, 'off')])
+        '--graph_tail', 'True' if args.graph_tail else 'False', '--step_graph', 'True' if args.step_graph else 'False'])
     if args.step_graph:
         args.profile = 0                                    # per-kernel events cannot be inserted into a replayed graph
     step_fn = TrainStep(targs, device, world)
@@ -527,7 +521,7 @@ def main():
         torch.distributed.barrier()
     # profile 1 (default): time only the kernels the roofline object reports -- every timed dispatch costs a small
     # pipeline bubble, and with ~25 library launches per step timing all of them would cost ~10 % of the step
-    hot = ('warp_forward', 'warp_backward', 'warp_backward_finish', 'warp_patch_l1_fused', 'warp_patch_l1_finish', 'prefetch')
+    hot = ('warp_forward', 'warp_backward', 'warp_backward_finish', 'warp_patch_l1_fused', 'warp_patch_l1_finish')
     _lib.profile_enable(bool(args.profile), only=None if args.profile == 2 else hot)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -588,51 +582,6 @@ def main():
             temps = forward_temperatures(device, batch['I_aug'], th_last, args.img_h, args.img_w)
         except Exception as e:                              # noqa: BLE001 -- an extra, must not lose the headline
             temps = {'error': '%s: %s' % (type(e).__name__, e)}
-    # The measured remedy for the cold frame, and why it is not the default (round 4): a few untimed steps with the frame
-    # prefetched -- by rider blocks of the DLT launch, and on the library's side stream -- kernel durations by dispatch events, then
-    # step time with and without, events off.
-    with_pf = None
-    if args.profile and world == 1 and not args.step_graph and not args.fused_patch and not args.traffic_child and not args.prefetch_frame:
-        try:
-            def steps_ms(n):
-                torch.cuda.synchronize(device)
-                t_a = time.perf_counter()
-                for _ in range(n):
-                    step_fn(batch)
-                torch.cuda.synchronize(device)
-                return (time.perf_counter() - t_a) / n * 1e3
-            with_pf = {}
-            alg_fwd = 2 * B * args.img_h * args.img_w * 3 * 4
-            for mode in ('dlt', 'side'):
-                step_fn.args.prefetch_frame = mode
-                steps_ms(3)
-                _lib.profile_enable(True, only=('warp_forward', 'prefetch', 'dlt_forward'))
-                steps_ms(10)
-                p3 = _lib.profile_read()
-                _lib.profile_enable(False)
-                ms_on = steps_ms(20)
-                us3 = p3['warp_forward'][0] / max(p3['warp_forward'][1], 1) * 1e3
-                with_pf[mode] = {'warp_forward_avg_us': round(us3, 2), 'frac': round(alg_fwd / (us3 * 1e-6) / HBM_PEAK, 4),
-                                 'dlt_forward_avg_us': round(p3['dlt_forward'][0] / max(p3['dlt_forward'][1], 1) * 1e3, 2),
-                                 'side_stream_prefetch_kernel_avg_us': (round(p3['prefetch'][0] / p3['prefetch'][1] * 1e3, 2)
-                                                                        if p3['prefetch'][1] else None),
-                                 'ms_per_step': round(ms_on, 3)}
-            step_fn.args.prefetch_frame = 'off'
-            steps_ms(3)
-            _lib.profile_enable(True, only=('warp_forward', 'dlt_forward'))
-            steps_ms(10)
-            p4 = _lib.profile_read()
-            _lib.profile_enable(False)
-            with_pf['off'] = {'warp_forward_avg_us': round(p4['warp_forward'][0] / max(p4['warp_forward'][1], 1) * 1e3, 2),
-                              'dlt_forward_avg_us': round(p4['dlt_forward'][0] / max(p4['dlt_forward'][1], 1) * 1e3, 2),
-                              'ms_per_step': round(steps_ms(20), 3)}
-            with_pf['note'] = ("--prefetch_frame dlt: rider blocks of the DLT-solve launch read I into the Infinity Cache (uh_dlt_forward_prefetch; "
-                               "the solve is latency-bound, no second stream); --prefetch_frame side: uh_prefetch_async on a side stream forked "
-                               "after fc1.  The warp then samples a warm frame.  Neither is the trainer default: see ms_per_step against 'off'.  "
-                               "3 + 10 + 20 untimed steps per mode after the timed region, same batch, same theta law")
-        except Exception as e:                              # noqa: BLE001 -- an extra, must not lose the headline
-            step_fn.args.prefetch_frame = 'off'
-            with_pf = {'error': '%s: %s' % (type(e).__name__, e)}
     loss_val = float(model.loss.detach())
 
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -715,11 +664,6 @@ def main():
                                 'note': 'whole train step (3 x forward FLOPs of the VGG regressor x global batch) / ms_per_step against the f32-input '
                                         'MFMA peak per GPU (v_mfma_f32_32x32x2_f32 = the f32 vector rate; gfx950 has no xf32 / TF32): the conv '
                                         'stack is stock MIOpen by north_star, the hand-written hot path is 1.5 % of the step'}
-    out['config']['frame_prefetch'] = {0: 'off', 1: 'side', 2: 'dlt'}.get(args.prefetch_frame, 'off')
-    if args.prefetch_frame and isinstance(out.get('roofline'), dict):
-        out['roofline']['input_state'] = ('NOT the trainer default: I is read into the 256 MB Infinity Cache before the warp samples it (--prefetch_frame '
-                                         '1: uh_prefetch_async on a side stream while fc2 and the DLT solve run; 2: rider blocks of the DLT-solve '
-                                         'launch): the in-step forward samples a WARM frame; its HBM read traffic moves to the prefetching launch')
     out['config']['warmup_seconds'] = round(warmup_s, 1)
     out['config']['tunable_gemm'] = ('on: torch.cuda.tunable picked the fully connected GEMMs (fc1 forward 142 -> 55 us; --tunable_gemm 0 = rounds 1-3)'
                                      if tuned_gemms else 'off')
@@ -740,8 +684,6 @@ def main():
                                 'asymptotically, the float4-copy yardstick; the fixed part is a third of this launch)'
                                 % (t_in, 100.0 * (t_in - temps['warm_us']) / span, temps['warm_us'], temps['cold_us']))
         out['roofline']['why_in_step_frac_is_below_the_warm_point'] = temps
-    if with_pf is not None and isinstance(out.get('roofline'), dict):
-        out['roofline']['with_frame_prefetch'] = with_pf
     if world > 1:
         out['config']['world_size'] = torch.distributed.get_world_size()
         out['config']['dist_backend'] = torch.distributed.get_backend()
@@ -770,11 +712,6 @@ def main():
                 out['roofline']['traffic_stale'] = False
                 out['roofline']['traffic_note'] = mt['_how'] + '; %d launches of the in-step shape seen' % hit['launches_seen']
                 out['roofline']['traffic_over_algorithmic'] = round(hit['hbm_bytes_per_launch'] / alg, 4)
-            pf = traffic_lookup(mt, 'prefetch_kernel', 256)
-            if pf is not None:                                  # the frame's HBM read now happens HERE, under the regressor's tail
-                out['roofline']['traffic_prefetch_kernel'] = pf['hbm_bytes_per_launch']
-                out['roofline']['traffic_forward_plus_prefetch_over_algorithmic'] = round(
-                    (hit['hbm_bytes_per_launch'] if hit else 0) / alg + pf['hbm_bytes_per_launch'] / alg, 4)
         if isinstance(out.get('config4_point'), dict) and 'error' not in out['config4_point']:
             for side, fam in (('traffic_fwd', 'warp_forward_kernel'), ('traffic_bwd', 'warp_backward_kernel')):
                 hit = traffic_lookup(mt, fam, blocks_of(128, 480, 640))

@@ -31,8 +31,19 @@
  *   - every `const float*` / `float*` / `const int*` below is a DEVICE pointer owned by the caller,
  *     contiguous, row-major, 4-byte aligned, unless the comment says HOST.  Images are NHWC.
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream); nothing synchronises, allocates or frees; no global mutable state other than the
- *     optional profiler below; entry points are thread-safe.
+ *     stream) and returns; nothing allocates or frees device memory.  The calls that SYNCHRONISE are
+ *     exactly two, both host-side read-backs: uh_dlt_zeroed_pairs (waits for `stream`) and
+ *     uh_profile_read (waits for the profiler's events).  uh_tail_run stream-captures on the first
+ *     sight of an argument set (host work, no device wait).
+ *   - state the library keeps between calls -- all of it:
+ *       (1) the optional launch profiler (uh_profile_*): a process-wide on/off flag, a mask, an event
+ *           pool and per-kernel totals behind one mutex; off by default;
+ *       (2) one device-side counter per device, the pairs zeroed by UH_DLT_ZERO_NONFINITE_GRAD
+ *           (written only when that flag is passed; read and cleared by uh_dlt_zeroed_pairs);
+ *       (3) per uh_tail_plan (owned by the caller, not global): its captured hipGraphs (LRU of 8) and
+ *           launch counters, behind the plan's mutex.
+ *     No library-owned streams, no events outside the profiler, no host or device allocations.
+ *   - entry points are thread-safe (uh_tail_run is serialised per plan; see its comment).
  *   - return value: 0 = ok; >0 = a hipError_t raised by the launch; <0 = argument error (UH_E_*).
  *   - arithmetic: IEEE f32, FP contraction OFF on the forward paths so that results are op-for-op
  *     those of the un-fused TF-CPU graph (see DESIGN.md "Numerics").
@@ -47,7 +58,7 @@
 extern "C" {
 #endif
 
-#define UH_ABI_VERSION 6
+#define UH_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define UH_API __attribute__((visibility("default")))
@@ -61,6 +72,7 @@ extern "C" {
 #define UH_E_CHANNELS    (-3)   /* C not in {1,2,3,4}                             */
 #define UH_E_WORKSPACE   (-4)   /* workspace missing or smaller than *_workspace_bytes() */
 #define UH_E_TOO_LARGE   (-5)   /* one image exceeds 2^31 bytes, or patch index range */
+#define UH_E_CAPTURING   (-6)   /* a synchronising call (uh_dlt_zeroed_pairs) on a stream that is being captured */
 
 /* flags for uh_dlt_* */
 #define UH_DLT_SOLVE_F32   0u   /* default: f32 partial-pivot LU, the tf.matrix_solve semantics  */
@@ -86,13 +98,6 @@ UH_API int uh_dlt_forward(const float* pts1, const float* h4p, float* H, float* 
 
 /* Gradient w.r.t. h4p.  Exactly one of dH / dtheta must be non-NULL: with dtheta the kernel first
  * folds dH = Minv^T dtheta M^T.  H is the forward output.                                        */
-/* The same launch with RIDER blocks that read `prefetch_bytes` bytes at `prefetch_ptr` once and discard them (ABI 6): the solve is
- * latency-bound and leaves HBM idle, the frame the warp samples next ends up in the 256 MB Infinity Cache -- uh_warp_forward on
- * it then costs 19 us instead of 27 (batch 64, 240x320).  No reference counterpart; prefetch_ptr NULL = uh_dlt_forward.        */
-UH_API int uh_dlt_forward_prefetch(const float* pts1, const float* h4p, float* H, float* theta,
-                            const float* M_host, const float* Minv_host, int B, unsigned flags,
-                            const void* prefetch_ptr, size_t prefetch_bytes, uh_stream_t stream);
-
 UH_API int uh_dlt_backward(const float* pts1, const float* h4p, const float* H,
                     const float* dH, const float* dtheta,
                     const float* M_host, const float* Minv_host,
@@ -100,9 +105,11 @@ UH_API int uh_dlt_backward(const float* pts1, const float* h4p, const float* H,
 
 /* How many pairs UH_DLT_ZERO_NONFINITE_GRAD has zeroed on the current device since the last reset (the one deliberate
  * departure from the reference, which lets tf.matrix_solve's NaN through, homography_model.py:242: the trainer prints
- * this so that the guard is never silent).  Synchronous: waits for the whole device (every stream), then takes the count
- * -- and with reset != 0 clears it -- in one atomic exchange: no increment is lost between the read and the clear.   */
-UH_API int uh_dlt_zeroed_pairs(unsigned long long* count, int reset);
+ * this so that the guard is never silent).  SYNCHRONOUS on `stream` (only): a one-thread kernel ordered after the work
+ * already enqueued there takes the count -- and with reset != 0 clears it -- in one atomic exchange, so no increment is
+ * lost between the read and the clear; launches still pending on other streams are counted by the next call.
+ * UH_E_CAPTURING when `stream` is being captured (call it at log time, outside any capture).                         */
+UH_API int uh_dlt_zeroed_pairs(unsigned long long* count, int reset, uh_stream_t stream);
 
 /* ---- Spatial transformer ----------------------------------------------------------------------
  * U [B,H,W,C], theta [B,9] -> out [B,oh,ow,C].  `condition` (device float[1], may be NULL) receives
@@ -166,19 +173,6 @@ UH_API int uh_prepare_inputs(const unsigned char* I_u8, const unsigned char* Ipr
                       const float* pts1, const float* mean3_host, const float* std3_host,
                       float* I_aug, float* Iprime_aug, float* I1, float* I2, float* I1_aug, float* I2_aug,
                       int* patch_idx, int B, int H, int W, int P, uh_stream_t stream);
-
-/* ---- Infinity-Cache prefetch of a frame (no reference counterpart: a scheduling hint for the 256 MB memory-side cache) ----
- * Reads `bytes` bytes at `ptr` once and discards them (a light grid: 256 workgroups of 16-byte loads).  Inside the train step
- * the frame U was last touched a whole conv stack ago; the same uh_warp_forward launch costs 33 us on a cold U and 20.6 us once
- * U has been read (profiles/r04_cold_forward_prefetch_probe.jsonl).  Enqueued on a SIDE stream under the fc layers / the DLT
- * solve, whose kernels leave HBM idle, the read is off the critical path.  Changes no memory; any alignment; bytes may be 0. */
-UH_API int uh_prefetch(const void* ptr, size_t bytes, uh_stream_t stream);
-/* The same on a library-owned non-blocking SIDE stream of the current device: the pass starts after the work enqueued on
- * `stream` so far (fork) and runs beside what `stream` is given next; uh_prefetch_join makes `stream` wait for it (no-op when
- * nothing is pending; optional -- the pass only reads).  Fork and join use events without the system-scope fence.  Inside a
- * stream capture uh_prefetch_async does nothing (a hint may be dropped).  One prefetch in flight per device.                */
-UH_API int uh_prefetch_async(const void* ptr, size_t bytes, uh_stream_t stream);
-UH_API int uh_prefetch_join(uh_stream_t stream);
 
 /* ---- all photometric losses in one pass, and the gradient of the trained one ----------------
  * pred, target [B,P,P] (one channel)  ->  out16[16] (device):
@@ -286,8 +280,7 @@ UH_API int    uh_bias_relu_pool_backward(const float* y, const float* gpooled, f
 #define UH_K_EPI_FWD       14
 #define UH_K_EPI_BWD       15
 #define UH_K_LOSS_BWD      16
-#define UH_K_PREFETCH      17
-#define UH_K_COUNT         18
+#define UH_K_COUNT         17
 /* on = 0: off; 1: time every kernel; otherwise a mask: bit (k + 1) set = time kernel UH_K_k only (timing a dispatch
  * costs a few us of pipeline bubble, so a throughput run times just the kernels it reports).  Returns the previous
  * on/off state; resets the counters.                                                                              */

@@ -79,12 +79,12 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert lib.uh_warp_backward_workspace_bytes(0, 240, 320, 3, 240, 320) == 0
     assert b'UH_E_WORKSPACE' in lib.uh_error_string(-4)
     assert lib.uh_kernel_name(2) == b'warp_forward'
-    # uh_prefetch (round 4): NULL refused; a range that holds no whole 16-byte chunk is a no-op that launches nothing
-    assert lib.uh_prefetch(None, 4096, None) == -1 and lib.uh_prefetch_async(None, 4096, None) == -1
-    assert lib.uh_dlt_forward_prefetch(None, one, one, None, None, None, 4, 0, one, 4096, None) == -1
-    assert lib.uh_dlt_forward_prefetch(one, one, one, None, None, None, 0, 0, one, 4096, None) == -2
-    assert lib.uh_prefetch(one, 0, None) == 0 and lib.uh_prefetch(C.c_void_p(1), 30, None) == 0
-    assert lib.uh_kernel_name(17) == b'prefetch' and lib.uh_kernel_name(18) == b'?'
+    assert lib.uh_kernel_name(16) == b'patch_loss_backward' and lib.uh_kernel_name(17) == b'?'
+    # round 5: the prefetch family (uh_prefetch, uh_prefetch_async, uh_prefetch_join, uh_dlt_forward_prefetch) is gone
+    for gone in ('uh_prefetch', 'uh_prefetch_async', 'uh_prefetch_join', 'uh_dlt_forward_prefetch'):
+        assert not hasattr(lib, gone), gone
+    assert lib.uh_dlt_zeroed_pairs(None, 0, None) == -1                                       # count is required
+    assert b'UH_E_CAPTURING' in lib.uh_error_string(-6)
     # entry points added after the first slice
     assert lib.uh_warp_forward_literal(one, one, None, 1, 8, 8, 3, 8, 8, None) == -1
     assert lib.uh_patch_losses_forward(one, one, one, None, one, one, 1 << 20, 2, 16, None) == -1   # h4p xor gt

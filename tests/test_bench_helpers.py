@@ -29,13 +29,11 @@ def test_traffic_lookup_tells_shapes_and_instantiations_apart(bench):
          'warp_forward_kernel<3, false, true>@4800': {'hbm_bytes_per_launch': 106, 'launches_seen': 9},
          'warp_forward_kernel<3, false, true>@38400': {'hbm_bytes_per_launch': 751, 'launches_seen': 61},
          'warp_backward_kernel<3, false, true, true>@1600': {'hbm_bytes_per_launch': 30, 'launches_seen': 8},
-         'warp_backward_kernel<3, false, true, false>@38400': {'hbm_bytes_per_launch': 747, 'launches_seen': 60},
-         'prefetch_kernel@256': {'hbm_bytes_per_launch': 59, 'launches_seen': 8}}
+         'warp_backward_kernel<3, false, true, false>@38400': {'hbm_bytes_per_launch': 747, 'launches_seen': 60}}
     assert bench.traffic_lookup(m, 'warp_forward_kernel', 4800)['hbm_bytes_per_launch'] == 106
     assert bench.traffic_lookup(m, 'warp_forward_kernel', 38400)['hbm_bytes_per_launch'] == 751
     assert bench.traffic_lookup(m, 'warp_backward_kernel', 38400)['hbm_bytes_per_launch'] == 747
     assert bench.traffic_lookup(m, 'warp_backward_kernel', 1600) is None            # PATCH mode: not the dense kernel
-    assert bench.traffic_lookup(m, 'prefetch_kernel', 256)['hbm_bytes_per_launch'] == 59
     assert bench.traffic_lookup(m, 'warp_forward_kernel', 123) is None
     assert bench.traffic_lookup({'error': 'rocprofv3 not found'}, 'warp_forward_kernel', 4800) is None
     assert bench.traffic_lookup(None, 'warp_forward_kernel', 4800) is None
@@ -44,13 +42,14 @@ def test_traffic_lookup_tells_shapes_and_instantiations_apart(bench):
 def test_committed_traffic_is_flagged_stale_when_the_kernel_sources_moved(bench, monkeypatch):
     """profiles/traffic_rNN.json carries build._fingerprint() of the sources it was measured on; a different loaded library =>
     `stale`.  (Files from before round 4 carry no fingerprint and always count as stale.)"""
-    f = os.path.join(ROOT, 'profiles', 'traffic_r04.json')
+    newest = next(n for n in bench.TRAFFIC_FILES if os.path.exists(os.path.join(ROOT, 'profiles', n)))
+    f = os.path.join(ROOT, 'profiles', newest)
     tr = json.load(open(f))
     assert '_fingerprint' in tr and '_provenance' in tr
     key = 'warp_forward_B64_240x320'
     monkeypatch.setattr(bench, 'library_fingerprint', lambda: tr['_fingerprint'])
     got = bench.committed_traffic(key)
-    assert got['file'] == 'profiles/traffic_r04.json' and got['stale'] is False
+    assert got['file'] == 'profiles/' + newest and got['stale'] is False
     assert got['hbm_bytes_per_launch'] == tr[key]['hbm_bytes_per_launch']
     # under the mid-training law a fifth of U is never sampled: the file must hold the TIMED law's bytes (0.90 x algorithmic),
     # not the near-identity replay's 0.997 x that rounds 1-3 quoted
@@ -83,21 +82,16 @@ def test_reference_schedule_result_is_read_from_the_committed_log(bench):
     assert 3.0 < r['mean_corner_error_px'] < 8.0 and 0.0 <= r['fail_percent'] < 1.0
 
 
-def test_timed_steps_stats_blocks(tmp_path):
-    """tools/timed_steps_stats.py on a synthetic kernel trace: W warm-up + K timed steps, a stand-alone DLT solve (no backward:
-    not a step), the 10-step round-1-law replay, then 33 steps with the frame prefetch and 23 without."""
+def _synthetic_trace(tmp_path, W, K):
     rows, t = [], [0]
 
     def k(name, dur):
         rows.append({'Kernel_Name': name, 'Start_Timestamp': t[0], 'End_Timestamp': t[0] + dur}); t[0] += dur + 100
 
-    def step(fwd_ns, prefetch=False):
+    def step(fwd_ns):
         k('void uh::dlt_forward_kernel<float>(...)', 5000)
-        if prefetch:
-            k('uh::prefetch_kernel(...)', 15000)
         k('void uh::warp_forward_kernel<3, false, true>(...)', fwd_ns)
         k('void uh::dlt_backward_kernel<float>(...)', 6000)
-    W, K = 2, 5
     for _ in range(W):
         k('naive_conv_find_trial', 300000000); step(40000)
     for _ in range(K):
@@ -105,28 +99,39 @@ def test_timed_steps_stats_blocks(tmp_path):
     k('void uh::dlt_forward_kernel<float>(...)', 5000)                 # th_last: a solve without a backward
     for _ in range(10):
         step(23000)
-    k('void uh::dlt_forward_kernel<float>(...)', 5000)
-    for _ in range(33):
-        step(18700, prefetch=True)
-    for _ in range(23):
-        step(27700)
+    k('void uh::dlt_forward_kernel<float>(...)', 5000)                 # the warp-only points: one more stand-alone solve
     f = tmp_path / 'kernel_trace.csv'
     with open(f, 'w', newline='') as fh:
         w = csv.DictWriter(fh, fieldnames=['Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
         w.writeheader(); w.writerows(rows)
+    return f
+
+
+def test_timed_steps_stats_blocks(tmp_path):
+    """tools/timed_steps_stats.py on a synthetic kernel trace: W warm-up + K timed steps, a stand-alone DLT solve (no backward:
+    not a step), then the 10-step round-1-law replay.  The output starts with the source fingerprint of the library."""
+    from unsuperviseddeephomographyral2018_amd import build
+    W, K = 2, 5
+    f = _synthetic_trace(tmp_path, W, K)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'timed_steps_stats.py'), str(f), str(W), str(K)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    head, body = r.stdout.split('\n', 1)
+    assert head.startswith('# _fingerprint: ' + build._fingerprint())
     got = {}
-    for row in csv.DictReader(io.StringIO(r.stdout)):
+    for row in csv.DictReader(io.StringIO(body)):
         if 'warp_forward' in row['Name']:
             got[row['Block'][:12]] = (int(row['Calls']), float(row['AverageNs']))
         assert 'naive_conv' not in row['Name']                         # find-mode trial kernels never enter
-    assert got['timed steps '] == (K, 27000.0)
-    assert got['replay under'] == (8, 23000.0)
-    assert got['mid-training'][1] in (18700.0, 27700.0) and len(got) >= 3
-    blocks = {row['Block'] for row in csv.DictReader(io.StringIO(r.stdout))}
-    assert any('WITH the frame prefetch' in b for b in blocks) and any('prefetch off again' in b for b in blocks)
+    assert got == {'timed steps ': (K, 27000.0), 'replay under': (8, 23000.0)}
+    # ... and the per-step breakdown of the same K timed steps (not the replay, not the warm-up)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'step_breakdown.py'), str(f), str(W), str(K)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0].startswith('# _fingerprint: ' + build._fingerprint())
+    assert 'steps averaged: %d' % K in lines[1] and 'sum of kernel durations per step 38.0 us' in lines[1]
+    assert any('27.0 us/step' in l and 'warp_forward' in l for l in lines) and not any('naive_conv' in l for l in lines)
 
 
 def test_regressor_flops_match_the_survey(bench):
@@ -135,11 +140,19 @@ def test_regressor_flops_match_the_survey(bench):
     assert bench.regressor_flops(64) < bench.regressor_flops(128) / 3.9
 
 
-def test_committed_traffic_file_was_measured_on_the_current_kernel_sources():
-    """The fallback for roofline.traffic must not go stale silently: profiles/traffic_r04.json stores build._fingerprint() of
-    the sources it was measured on.  Editing csrc/ or include/ (even a comment: the header is part of the build stamp) makes
-    this fail until `tools/gpu_session.sh rNN traffic` has been re-run and its file committed -- or the name of the newest
-    file in bench.TRAFFIC_FILES bumped."""
+EVIDENCE_ROUND = 'r05'        # the round whose profiles/ evidence must have been taken on the kernel sources in the tree
+
+
+def test_committed_evidence_was_measured_on_the_current_kernel_sources():
+    """The evidence the documents quote must not go stale silently: profiles/traffic_rNN.json (the fallback for
+    roofline.traffic), rNN_bench_kernel_stats_timed_steps.csv and rNN_step_breakdown.txt each store build._fingerprint() of the
+    sources they were measured on.  Editing csrc/ or include/ (even a comment: the header is part of the build stamp) makes
+    this fail until `tools/gpu_session.sh rNN rocprof traffic` has been re-run and its files committed."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from _trace_steps import read_fingerprint
     from unsuperviseddeephomographyral2018_amd import build
-    tr = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r04.json')))
-    assert tr['_fingerprint'] == build._fingerprint()
+    fp = build._fingerprint()
+    tr = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_%s.json' % EVIDENCE_ROUND)))
+    assert tr['_fingerprint'] == fp
+    for name in ('%s_bench_kernel_stats_timed_steps.csv' % EVIDENCE_ROUND, '%s_step_breakdown.txt' % EVIDENCE_ROUND):
+        assert read_fingerprint(os.path.join(ROOT, 'profiles', name)) == fp, name

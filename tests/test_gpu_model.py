@@ -433,16 +433,13 @@ def test_conv_bias_relu_epilogue_equals_torch(pkg, dev):
         assert (ga - gb).abs().max() <= (1e-3 if tight else 5e-2) * max(1e-6, float(gb.abs().max())), n
 
 
-@pytest.mark.parametrize('prefetch', ['False', 'True'])
-def test_whole_step_hipgraph_trains(pkg, dev, prefetch):
+def test_whole_step_hipgraph_trains(pkg, dev):
     """--step_graph: the whole training step (convs, epilogues, hot path, capturable fused Adam) captured into one
     hipGraph and replayed.  The replayed steps must keep training (loss on a fixed batch goes down) and new batch data
-    copied into the static buffers must be what the graph consumes.  With --prefetch_frame True the side-stream hint is given
-    in the eager warm-up steps and silently dropped inside the capture (uh_prefetch_async under a capturing stream)."""
+    copied into the static buffers must be what the graph consumes."""
     hm, synthetic, drv = pkg
     args = drv.build_parser().parse_args(['--batch_size', str(B), '--img_h', str(H), '--img_w', str(W), '--patch_size', str(P),
-                                          '--rho', str(RHO), '--loss_type', 'l1_loss', '--step_graph', 'True', '--lr', '1e-4',
-                                          '--prefetch_frame', prefetch])
+                                          '--rho', str(RHO), '--loss_type', 'l1_loss', '--step_graph', 'True', '--lr', '1e-4'])
     torch.manual_seed(0)
     step = drv.TrainStep(args, dev, 1)
     batch = synthetic.make_batch(B, H, W, P, RHO, seed=21, device=dev)
@@ -567,52 +564,32 @@ def test_train_entry_point_from_generator_pool_and_disk(pkg, dev, tmp_path, caps
     assert '===> Start step: 6' in out
 
 
-def test_frame_prefetch_is_a_hint_same_bits_and_untouched_memory(pkg, dev):
-    """uh_prefetch / ops.prefetch_frame (round 4): reading I into the Infinity Cache on a side stream under the regressor's tail
-    changes no memory and no result -- pred_h4p, H, pred_I2, every loss value and d loss / d pred_h4p are bit-equal with the
-    prefetch on (forked after fc1, or before it) and off; odd pointers / sizes through the C ABI read inside the range only
-    (canaries either side stay intact because nothing is ever written)."""
+def test_zeroed_pairs_counter_is_read_on_the_callers_stream_and_refuses_a_capture(dev):
+    """uh_dlt_zeroed_pairs (ABI 7): synchronous on the given stream only -- a count taken on a side stream sees the backward
+    launched there before it; reset clears; a capturing stream is refused with UH_E_CAPTURING and the capture survives."""
     import ctypes as C
-    import os
-    hm, synthetic, _ = pkg
     from unsuperviseddeephomographyral2018_amd import _lib, ops
     lib = _lib.load()
-    batch = synthetic.make_batch(B, H, W, P, RHO, seed=31, device=dev)
-    torch.manual_seed(3)
-    net = hm.VGGRegressor(P, dropout_p=0.0).to(dev).to(memory_format=torch.channels_last)
-    keep_det = torch.backends.cudnn.deterministic
-    torch.backends.cudnn.deterministic = True
-    outs = {}
-    try:
-        for tag, pf, at in (('off', False, 'fc2'), ('after_fc1', True, 'fc2'), ('before_fc1', True, 'fc1'), ('dlt_riders', 'dlt', 'fc2')):
-            os.environ['UH_PREFETCH_AT'] = at
-            m = hm.HomographyModel(params(hm, 'train', B, P, W, H, 'l1_loss'), *synthetic.model_args(batch), net=net,
-                                   prefetch_frame=pf)
-            assert m.prefetch_mode == {False: 'off', True: 'side', 'dlt': 'dlt'}[pf] and m.prefetch_frame == (pf is True)
-            (g,) = torch.autograd.grad(m.loss, m.pred_h4p)
-            outs[tag] = [t.detach().clone() for t in (m.pred_h4p, m.H_mat, m.pred_I2, m.l1_loss, m.rec_loss, m.ssim_loss, g)]
-    finally:
-        os.environ.pop('UH_PREFETCH_AT', None)
-        torch.backends.cudnn.deterministic = keep_det
+    _lib.dlt_zeroed_pairs(reset=True)
+    pts1 = torch.tensor([[10., 10., 50., 10., 50., 50., 10., 50.]] * 3, device=dev)
+    h4p = torch.zeros(3, 8, device=dev)
+    h4p[1] = 1e30                                                          # products overflow -> inf - inf -> NaN gradient
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        hp = h4p.clone().requires_grad_(True)
+        Hm, theta = ops.solve_dlt(pts1, hp, 64, 64, zero_nonfinite_grad=True)
+        theta.sum().backward()
+        n = _lib.dlt_zeroed_pairs(reset=False)                            # current stream = side
+        assert n == 1 and torch.all(hp.grad[1] == 0) and torch.isfinite(hp.grad).all()
+        assert _lib.dlt_zeroed_pairs(reset=True) == 1 and _lib.dlt_zeroed_pairs() == 0
+        g = torch.cuda.CUDAGraph()
+        buf = torch.zeros(4, device=dev)
+        with torch.cuda.graph(g, stream=side):
+            buf += 1
+            cnt = C.c_ulonglong(7)
+            rc = lib.uh_dlt_zeroed_pairs(C.byref(cnt), 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            assert rc == -6 and cnt.value == 7                            # refused, nothing written, capture intact
+        g.replay()
     torch.cuda.synchronize(dev)
-    for tag in ('after_fc1', 'before_fc1', 'dlt_riders'):
-        for a, b in zip(outs['off'], outs[tag]):
-            assert torch.equal(a, b), tag
-    # the C entry point on ranges that are neither 16-byte aligned nor a multiple of 16 bytes long
-    buf = torch.arange(4096, dtype=torch.float32, device=dev)
-    ref = buf.clone()
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    for off, nbytes in ((0, 4096 * 4), (4, 4096 * 4 - 8), (12, 37), (8, 0), (4, 15)):
-        _lib.check(lib.uh_prefetch(C.c_void_p(buf.data_ptr() + off), nbytes, st), 'uh_prefetch')
-    ops.prefetch_frame(buf)
-    ops.join_prefetch(dev)
-    # ... and the rider-block form: the DLT solve with a prefetch range returns the same H / theta bits, touches nothing
-    pts1, h4p = batch['pts1'], torch.randn(B, 8, device=dev) * 5
-    Ha, ta = ops.solve_dlt(pts1, h4p, W, H)
-    for rng in (buf, buf[1:], buf[:7], batch['I_aug']):
-        Hb, tb = ops.solve_dlt(pts1, h4p, W, H, prefetch=rng if rng.is_contiguous() else None)
-        assert torch.equal(Ha, Hb) and torch.equal(ta, tb)
-    torch.cuda.synchronize(dev)
-    assert torch.equal(buf, ref)
-    with pytest.raises(_lib.UHError):
-        ops.prefetch_frame(torch.zeros(4))                       # a host tensor: no CPU fallback, not even for a hint
+    assert torch.all(buf == 1)

@@ -22,7 +22,6 @@
 #   dpsmooth / dpnoise   the two data-dependent DP tests on smooth textures (pinned / default solvers) / on the default solvers
 #   coldv:V1,V2     cold-forward A/B/A/B of the shipped library against variants (batches 64, 128)
 #   power:LIBS:K    tools/power_ab.py: duration + socket power + energy per launch of kernel K (fwd | bwd) per library build
-#   prefetch_ab     the side-stream frame prefetch in the train step: off / join / fire-and-forget / profiler events with the fence
 #   trace:V         per-wave phase trace with the -DUH_WARP_TRACE variant V (tools/trace_waves.py)
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 TAG=$1; shift
@@ -46,7 +45,7 @@ for ST in "$@"; do
     rocprof)
             ( cd /tmp && rm -rf /tmp/prof_$TAG && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench --output-format csv -- $BENCH > /root/repo/gpurun_out/${TAG}_bench_line_under_rocprof.json 2>/dev/null )
             cp $(find /tmp/prof_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_bench_kernel_stats.csv 2>/dev/null
-            python tools/step_breakdown.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 20 60 > gpurun_out/${TAG}_step_breakdown.txt 2>&1
+            python tools/step_breakdown.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 5 30 60 > gpurun_out/${TAG}_step_breakdown.txt 2>&1
             python tools/timed_steps_stats.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 5 30 > gpurun_out/${TAG}_bench_kernel_stats_timed_steps.csv 2> gpurun_out/${TAG}_timed_steps.err
             grep -E "warp_|Block" gpurun_out/${TAG}_bench_kernel_stats_timed_steps.csv | cut -c1-260 ;;
     rocprof_c4)
@@ -85,18 +84,6 @@ for ST in "$@"; do
             done ;;
     cold)   timeout 600 python tools/cold_forward.py --tag $TAG ${A1:+--batches ${A1//,/,}} > gpurun_out/${TAG}_cold_forward.jsonl 2> gpurun_out/${TAG}_cold_forward.err; cat gpurun_out/${TAG}_cold_forward.jsonl | cut -c1-260; tail -3 gpurun_out/${TAG}_cold_forward.err ;;
     train_ref) TAG=$TAG bash tools/train_reference_schedule.sh ;;
-    prefetch_ab) : > gpurun_out/${TAG}_prefetch_ab.jsonl
-            # prefetch on/off, join / fire-and-forget, and the profiler's events with / without the system-scope fence
-            for rep in 1 2; do for V in "0 1 0" "1 1 0" "1 0 0" "0 1 1"; do set -- $V
-              UH_PREFETCH_JOIN=$2 UH_PROF_FENCE=$3 timeout 400 python bench.py --prefetch_frame $1 --profile ${PROFILE:-1} --steps 60 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --traffic 0 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); k=d['roofline']['kernels']
-print(json.dumps({'prefetch': $1, 'join': $2, 'prof_fence': $3, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step'], 'frac': d['roofline']['frac'], 'us': {n: k[n]['avg_us'] for n in k if n in ('warp_forward','warp_backward','warp_backward_finish','prefetch')}, 'temps': {a: b for a, b in (d['roofline'].get('why_in_step_frac_is_below_the_warm_point') or {}).items() if a.endswith('_us')}}))" >> gpurun_out/${TAG}_prefetch_ab.jsonl
-            done; done
-            for P0 in 0 1; do timeout 400 python bench.py --prefetch_frame $P0 --profile 0 --steps 60 --cpu_baseline 0 --north_star 0 --config4 0 --quality 0 --traffic 0 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print(json.dumps({'prefetch': $P0, 'profile': 0, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step']}))" >> gpurun_out/${TAG}_prefetch_ab.jsonl; done
-            cat gpurun_out/${TAG}_prefetch_ab.jsonl ;;
     dpsmooth) for ND in 0 1; do UH_TEST_TEXTURE=smooth UH_TEST_NONDET=$ND timeout 600 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line -k "l1_equals or h_loss" > gpurun_out/${TAG}_pytest_dp_smooth_nondet$ND.log 2>&1; echo "smooth texture, default (non-deterministic) solvers allowed = $ND"; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_smooth_nondet$ND.log | cut -c1-700; done ;;
     dpnoise) UH_TEST_NONDET=1 timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=line > gpurun_out/${TAG}_pytest_dp_product_default_solvers.log 2>&1; grep -E "world 2|passed|failed" gpurun_out/${TAG}_pytest_dp_product_default_solvers.log | cut -c1-900 ;;
     power)  timeout 900 python tools/power_ab.py --libs ${A1:-shipped} --kernel ${A2:-bwd} --seconds 4 --reps 2 > gpurun_out/${TAG}_power_${A2:-bwd}.jsonl 2> gpurun_out/${TAG}_power.err; cat gpurun_out/${TAG}_power_${A2:-bwd}.jsonl ;;

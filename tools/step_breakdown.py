@@ -1,21 +1,29 @@
 #!/usr/bin/env python
-"""Steady-state per-step GPU time by kernel from a rocprofv3 --kernel-trace CSV of bench.py.
-Steps are delimited by uh::dlt_forward_kernel<float> (once per step); the last K full steps are averaged, so the
-MIOpen find-mode trial kernels of the warm-up never enter.  usage: step_breakdown.py kernel_trace.csv [K] [top]"""
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if 'dlt_forward_kernel<float>' in r['Kernel_Name']]
-lo, hi = marks[-K - 1], marks[-1]
-sel = rows[lo:hi]
+"""Steady-state per-step GPU time by kernel from a rocprofv3 --kernel-trace CSV of `bench.py --steps K --warmup W`: the K
+TIMED steps (tools/_trace_steps.py delimits them), so neither the MIOpen find-mode trial kernels of the warm-up nor the
+untimed replays bench.py appends enter.  First line: `# _fingerprint: <sha256>` of the traced library's kernel sources.
+usage: step_breakdown.py kernel_trace.csv W K [top]"""
+import collections
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _trace_steps import fingerprint, load_steps  # noqa: E402
+
+rows, spans = load_steps(sys.argv[1])
+W, K = int(sys.argv[2]), int(sys.argv[3])
+top = int(sys.argv[4]) if len(sys.argv) > 4 else 40
+if len(spans) < W + K + 1:
+    sys.exit('only %d steps found, need warm-up %d + timed %d + one more to close the last span' % (len(spans), W, K))
+sel = spans[W:W + K]
 acc = collections.defaultdict(lambda: [0.0, 0])
-for r in sel:
-    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    a = acc[r['Kernel_Name'][:120]]; a[0] += d; a[1] += 1
-span = (int(rows[hi]['Start_Timestamp']) - int(rows[lo]['Start_Timestamp'])) / 1e3 / K
+for a, b in sel:
+    for r in rows[a:b]:
+        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        e = acc[r['Kernel_Name'][:120]]; e[0] += d; e[1] += 1
+span = (int(rows[spans[W + K][0]]['Start_Timestamp']) - int(rows[sel[0][0]]['Start_Timestamp'])) / 1e3 / K
 busy = sum(v[0] for v in acc.values()) / K
-print('steps averaged: %d   wall per step %.1f us   sum of kernel durations per step %.1f us' % (K, span, busy))
+print('# _fingerprint: %s  (kernel sources of the traced library; W=%d K=%d)' % (fingerprint(), W, K))
+print('steps averaged: %d (the timed region)   wall per step %.1f us   sum of kernel durations per step %.1f us' % (K, span, busy))
 for name, (t, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:top]:
     print('%9.1f us/step %6.1f launches/step avg %8.1f us  %s' % (t / K, n / K, t / n, name))

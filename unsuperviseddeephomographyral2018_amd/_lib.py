@@ -7,14 +7,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UH_LIB_PATH lets a developer A/B a differently-built copy of the SAME library (tools/); it is not a fallback.
 LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hotpath.so')
 
-UH_ABI_VERSION = 6
+UH_ABI_VERSION = 7
 UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
 UH_DLT_ZERO_NONFINITE_GRAD = 8
 UH_TAIL_FUSED_PATCH = 2
 UH_TAIL_GRAPH = 4
 LOSS_KINDS = {'rec_loss': 0, 'ssim_loss': 1, 'l1_loss': 2, 'l1_smooth_loss': 3, 'ncc_loss': 4}
-KERNEL_COUNT = 18
+KERNEL_COUNT = 17
 
 _p = C.c_void_p
 _i = C.c_int
@@ -26,9 +26,8 @@ SIGNATURES = {
     'uh_abi_version': (_i, []),
     'uh_error_string': (C.c_char_p, [_i]),
     'uh_dlt_forward': (_i, [_p, _p, _p, _p, _p, _p, _i, _u, _p]),
-    'uh_dlt_forward_prefetch': (_i, [_p, _p, _p, _p, _p, _p, _i, _u, _p, _z, _p]),
     'uh_dlt_backward': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _u, _p]),
-    'uh_dlt_zeroed_pairs': (_i, [_p, _i]),
+    'uh_dlt_zeroed_pairs': (_i, [_p, _i, _p]),
     'uh_warp_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'uh_warp_forward_literal': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'uh_warp_backward_workspace_bytes': (_z, [_i, _i, _i, _i, _i, _i]),
@@ -43,9 +42,6 @@ SIGNATURES = {
     'uh_l1_loss_forward': (_i, [_p, _p, _p, _p, _z, _z, _p]),
     'uh_l1_loss_backward': (_i, [_p, _p, _p, _p, _z, _p]),
     'uh_prepare_inputs': (_i, [_p] * 13 + [_i, _i, _i, _i, _p]),
-    'uh_prefetch': (_i, [_p, _z, _p]),
-    'uh_prefetch_async': (_i, [_p, _z, _p]),
-    'uh_prefetch_join': (_i, [_p]),
     'uh_patch_losses_workspace_bytes': (_z, [_i, _i]),
     'uh_patch_losses_forward': (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     'uh_patch_loss_backward': (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p]),
@@ -103,13 +99,18 @@ KERNEL_IDS = {'dlt_forward': 0, 'dlt_backward': 1, 'warp_forward': 2, 'warp_back
               'gray_patch_forward': 5, 'gray_patch_backward': 6, 'l1_forward': 7, 'l1_backward': 8,
               'warp_patch_l1_fused': 9, 'warp_patch_l1_finish': 10, 'patch_losses': 11, 'patch_losses_finish': 12,
               'prepare_inputs': 13, 'bias_relu_forward': 14, 'bias_relu_backward': 15,
-              'patch_loss_backward': 16, 'prefetch': 17}
+              'patch_loss_backward': 16}
 
 
-def dlt_zeroed_pairs(reset=False):
-    """Pairs whose d loss / d pred_h4p UH_DLT_ZERO_NONFINITE_GRAD zeroed on the current device since the last reset."""
+def dlt_zeroed_pairs(reset=False, stream=None):
+    """Pairs whose d loss / d pred_h4p UH_DLT_ZERO_NONFINITE_GRAD zeroed on the current device since the last reset.
+    Synchronous on `stream` (a raw hipStream_t value; None = torch's current stream) -- log time only, and never while that
+    stream is being captured (the library refuses with UH_E_CAPTURING instead of invalidating the capture)."""
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream
     n = C.c_ulonglong(0)
-    check(load().uh_dlt_zeroed_pairs(C.byref(n), 1 if reset else 0), 'uh_dlt_zeroed_pairs')
+    check(load().uh_dlt_zeroed_pairs(C.byref(n), 1 if reset else 0, C.c_void_p(stream)), 'uh_dlt_zeroed_pairs')
     return int(n.value)
 
 

@@ -8,7 +8,6 @@
 // instead of ~40 TF ops, and bit-reproducible results.
 #include "uh_device.h"
 #include "uh_host.h"
-#include <algorithm>
 
 namespace uh {
 
@@ -93,29 +92,11 @@ __device__ __forceinline__ void sandwich3(const Mat3& L, const float X[9], const
             out[i * 3 + j] = (tmp[i * 3] * R.a[j] + tmp[i * 3 + 1] * R.a[3 + j]) + tmp[i * 3 + 2] * R.a[6 + j];
 }
 
-// RIDER blocks (uh_dlt_forward_prefetch): the solve is latency-bound -- ceil(B/4) blocks of dependent 64-lane shuffles, 5 us in
-// which HBM idles -- so the same launch can carry blocks [nblk_dlt, gridDim.x) that read-and-discard the frame the warp is
-// about to sample, leaving it in the 256 MB Infinity Cache.  No second stream, no event: the side-stream form of the same
-// prefetch costs the train step 60 - 90 us of cross-queue overhead (DESIGN.md 3.1 "Round 4").  The solver blocks come first
-// in dispatch order and are not delayed by the riders.
 template <typename T>
 __global__ __launch_bounds__(256) void dlt_forward_kernel(const float* __restrict__ pts1,
                                                           const float* __restrict__ h4p,
                                                           float* __restrict__ H, float* __restrict__ theta,
-                                                          Mat3 M, Mat3 Minv, int B, const uint4* __restrict__ pf, size_t pf_n16,
-                                                          int nblk_dlt) {
-    if ((int)blockIdx.x >= nblk_dlt) {
-        const size_t stride = (size_t)(gridDim.x - nblk_dlt) * 256;
-        size_t i = (size_t)((int)blockIdx.x - nblk_dlt) * 256 + threadIdx.x;
-        unsigned acc = 0;
-        for (; i + 3 * stride < pf_n16; i += 4 * stride) {
-            const uint4 a = pf[i], b = pf[i + stride], c = pf[i + 2 * stride], d = pf[i + 3 * stride];
-            acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
-        }
-        for (; i < pf_n16; i += stride) { const uint4 a = pf[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
-        if (acc == 0x9e3779b9u && pf_n16 == ~(size_t)0) H[0] = 0.f;        // never true (pf_n16 < 2^60): keeps the loads alive
-        return;
-    }
+                                                          Mat3 M, Mat3 Minv, int B) {
     const int sys = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sys >= B) return;                                   // whole wave exits together
     const int lane = threadIdx.x & 63;
@@ -210,37 +191,21 @@ static Mat3 load_mat3(const float* host, bool transpose) {
     return m;
 }
 
-extern "C" int uh_dlt_forward_prefetch(const float* pts1, const float* h4p, float* H, float* theta,
-                                       const float* M_host, const float* Minv_host, int B, unsigned flags,
-                                       const void* prefetch_ptr, size_t prefetch_bytes, uh_stream_t stream) {
+extern "C" int uh_dlt_forward(const float* pts1, const float* h4p, float* H, float* theta,
+                              const float* M_host, const float* Minv_host, int B, unsigned flags,
+                              uh_stream_t stream) {
     if (!pts1 || !h4p || !H) return UH_E_NULL;
     if (theta && (!M_host || !Minv_host)) return UH_E_NULL;
     if (B <= 0) return UH_E_SHAPE;
     Mat3 M = load_mat3(M_host, false), Minv = load_mat3(Minv_host, false);
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (B + 3) / 4;
-    // whole 16-byte chunks inside [prefetch_ptr, prefetch_ptr + prefetch_bytes)
-    const uint4* pf = nullptr;
-    size_t n16 = 0;
-    if (prefetch_ptr && prefetch_bytes >= 32) {
-        const uintptr_t a0 = ((uintptr_t)prefetch_ptr + 15) & ~(uintptr_t)15;
-        const uintptr_t e0 = ((uintptr_t)prefetch_ptr + prefetch_bytes) & ~(uintptr_t)15;
-        if (e0 > a0) { pf = (const uint4*)a0; n16 = (size_t)(e0 - a0) / 16; }
-    }
-    const int riders = n16 ? (int)std::min<size_t>(1024, (n16 + 255) / 256) : 0;     // 4 per CU: enough loads in flight for ~6 TB/s
-    dim3 grid(nblk + riders), block(256);
+    dim3 grid((B + 3) / 4), block(256);
     ProfScope prof(UH_K_DLT_FWD, s);
     if (flags & UH_DLT_SOLVE_F64)
-        hipLaunchKernelGGL(dlt_forward_kernel<double>, grid, block, 0, s, pts1, h4p, H, theta, M, Minv, B, pf, n16, nblk);
+        hipLaunchKernelGGL(dlt_forward_kernel<double>, grid, block, 0, s, pts1, h4p, H, theta, M, Minv, B);
     else
-        hipLaunchKernelGGL(dlt_forward_kernel<float>, grid, block, 0, s, pts1, h4p, H, theta, M, Minv, B, pf, n16, nblk);
+        hipLaunchKernelGGL(dlt_forward_kernel<float>, grid, block, 0, s, pts1, h4p, H, theta, M, Minv, B);
     return (int)hipGetLastError();
-}
-
-extern "C" int uh_dlt_forward(const float* pts1, const float* h4p, float* H, float* theta,
-                              const float* M_host, const float* Minv_host, int B, unsigned flags,
-                              uh_stream_t stream) {
-    return uh_dlt_forward_prefetch(pts1, h4p, H, theta, M_host, Minv_host, B, flags, nullptr, 0, stream);
 }
 
 extern "C" int uh_dlt_backward(const float* pts1, const float* h4p, const float* H, const float* dH,
@@ -262,17 +227,20 @@ extern "C" int uh_dlt_backward(const float* pts1, const float* h4p, const float*
     return (int)hipGetLastError();
 }
 
-extern "C" int uh_dlt_zeroed_pairs(unsigned long long* count, int reset) {
-    // synchronous: call it at log time, never inside a stream capture.  hipDeviceSynchronize first, so that kernels already
-    // enqueued on ANY stream -- also hipStreamNonBlocking ones, which the NULL stream does not order against -- are counted;
-    // then one atomicExch takes and clears the counter (pairs zeroed by launches racing with this call are simply counted by
-    // the next one: nothing is lost, nothing is counted twice)
+extern "C" int uh_dlt_zeroed_pairs(unsigned long long* count, int reset, uh_stream_t stream) {
+    // Synchronous on `stream` ONLY (rounds 2-4 synchronised the whole device and launched on the NULL stream, which also
+    // stalled the dataloader's upload stream at every log line): one atomicExch kernel ordered after the work already
+    // enqueued on `stream` takes (and clears) the counter, an async copy brings it to the host, the stream is waited for.
+    // Pairs zeroed by launches on OTHER streams that have not executed yet are counted by the next call: nothing is lost,
+    // nothing is counted twice.  A capturing stream is refused (a synchronising call would invalidate the capture).
     if (!count) return UH_E_NULL;
-    hipError_t e = hipDeviceSynchronize();
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return UH_E_CAPTURING;
+    hipLaunchKernelGGL(uh::dlt_take_zeroed_kernel, dim3(1), dim3(1), 0, s, reset ? 1 : 0);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(uh::dlt_take_zeroed_kernel, dim3(1), dim3(1), 0, (hipStream_t)0, reset ? 1 : 0);
-    e = hipGetLastError();
+    e = hipMemcpyFromSymbolAsync(count, HIP_SYMBOL(uh::g_dlt_zeroed_taken), sizeof(*count), 0, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return (int)e;
-    e = hipMemcpyFromSymbol(count, HIP_SYMBOL(uh::g_dlt_zeroed_taken), sizeof(*count));
-    return (int)e;
+    return (int)hipStreamSynchronize(s);
 }

@@ -165,88 +165,9 @@ void prof_end(int kernel, hipStream_t s) {
     }
 }
 
-// Read-and-discard pass over [p, p + n16*16): brings the lines into the memory-side Infinity Cache (and the L2 of whichever
-// XCD ran the block).  A FIXED light grid (256 blocks: one per CU) walks the range with 16-byte loads, four in flight per
-// thread; the xor of what was read goes to `sink` only under a condition that never holds, which keeps the loads alive.
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned acc = 0;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
-    }
-    for (; i < n16; i += stride) { const uint4 a = p[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
-    if (sink != nullptr && acc == 0x9e3779b9u && n16 == ~(size_t)0) *sink = acc;      // never true: n16 < 2^60
-}
-
 }  // namespace uh
 
 using namespace uh;
-
-extern "C" int uh_prefetch(const void* ptr, size_t bytes, uh_stream_t stream) {
-    if (!ptr) return UH_E_NULL;
-    // whole 16-byte chunks inside [ptr, ptr + bytes): the first bytes up to alignment and a tail < 16 B are left out
-    const uintptr_t a = ((uintptr_t)ptr + 15) & ~(uintptr_t)15;
-    const uintptr_t e = ((uintptr_t)ptr + bytes) & ~(uintptr_t)15;
-    if (e <= a) return 0;
-    const size_t n16 = (size_t)(e - a) / 16;
-    hipStream_t s = (hipStream_t)stream;
-    launch_timed(UH_K_PREFETCH, prefetch_kernel, dim3(256), dim3(256), s, (const uint4*)a, n16, (unsigned*)nullptr);
-    return (int)hipGetLastError();
-}
-
-// ---- the same on a library-owned SIDE stream, forked from / joined to the caller's stream ----------------------------------
-// Fork and join are events WITHOUT the system-scope fence (hipEventDisableTiming | hipEventDisableSystemFence): a default event
-// writes back and invalidates the caches when it completes, which cost the train step ~70 us per prefetch when the same
-// fork / join was built from torch's default events (profiles/r04_prefetch_ab.jsonl) -- ten times what the prefetch saves.
-namespace {
-struct SideState { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, done = nullptr; bool pending = false; };
-SideState g_side[64];
-std::mutex g_side_mu;
-int side_state(SideState** out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return UH_E_SHAPE;
-    SideState& st = g_side[dev];
-    if (!st.stream) {
-        if ((e = hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking)) != hipSuccess) return (int)e;
-        const unsigned fl = hipEventDisableTiming | hipEventDisableSystemFence;
-        if ((e = hipEventCreateWithFlags(&st.fork, fl)) != hipSuccess) return (int)e;
-        if ((e = hipEventCreateWithFlags(&st.done, fl)) != hipSuccess) return (int)e;
-    }
-    *out = &st;
-    return 0;
-}
-}  // namespace
-
-extern "C" int uh_prefetch_async(const void* ptr, size_t bytes, uh_stream_t stream) {
-    if (!ptr) return UH_E_NULL;
-    hipStream_t s = (hipStream_t)stream;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-        return 0;                                   // a hint: inside a stream capture it is simply not given
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    SideState* st = nullptr;
-    if (int e = side_state(&st)) return e;
-    hipError_t e;
-    if ((e = hipEventRecord(st->fork, s)) != hipSuccess) return (int)e;            // fork: after the caller's work so far
-    if ((e = hipStreamWaitEvent(st->stream, st->fork, 0)) != hipSuccess) return (int)e;
-    if (int r = uh_prefetch(ptr, bytes, (uh_stream_t)st->stream)) return r;
-    if ((e = hipEventRecord(st->done, st->stream)) != hipSuccess) return (int)e;
-    st->pending = true;
-    return 0;
-}
-
-extern "C" int uh_prefetch_join(uh_stream_t stream) {
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    SideState* st = nullptr;
-    if (int e = side_state(&st)) return e;
-    if (!st->pending) return 0;
-    st->pending = false;
-    return (int)hipStreamWaitEvent((hipStream_t)stream, st->done, 0);
-}
 
 extern "C" int uh_abi_version(void) { return UH_ABI_VERSION; }
 
@@ -258,6 +179,7 @@ extern "C" const char* uh_error_string(int code) {
         case UH_E_CHANNELS: return "UH_E_CHANNELS: C must be 1..4";
         case UH_E_WORKSPACE: return "UH_E_WORKSPACE: workspace missing or too small";
         case UH_E_TOO_LARGE: return "UH_E_TOO_LARGE: image or index range exceeds 32-bit addressing";
+        case UH_E_CAPTURING: return "UH_E_CAPTURING: a synchronising call on a stream that is being captured";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown uh error";
     }
 }
@@ -267,7 +189,7 @@ extern "C" const char* uh_kernel_name(int k) {
                                             "warp_backward_finish", "gray_patch_forward", "gray_patch_backward",
                                             "l1_forward", "l1_backward", "warp_patch_l1_fused", "warp_patch_l1_finish",
                                             "patch_losses", "patch_losses_finish", "prepare_inputs",
-                                            "bias_relu_forward", "bias_relu_backward", "patch_loss_backward", "prefetch"};
+                                            "bias_relu_forward", "bias_relu_backward", "patch_loss_backward"};
     return (k >= 0 && k < UH_K_COUNT) ? names[k] : "?";
 }
 

@@ -79,10 +79,6 @@ def build_parser():
                    help='train mode: a pair whose d loss / d pred_h4p is NaN / Inf (degenerate predicted corners) contributes '
                         'no gradient instead of poisoning every variable (UH_DLT_ZERO_NONFINITE_GRAD).  False = the '
                         'reference\'s behaviour: tf.matrix_solve + autodiff pass the NaN on.  The log line counts the pairs.')
-    p.add_argument('--prefetch_frame', type=str, default='off',
-                   help="read I into the 256 MB Infinity Cache before the warp samples it (a scheduling hint, same bits): 'off' (default), "
-                        "'dlt' = rider blocks of the DLT-solve launch do the read, 'side' (or True) = a side stream forked after fc1 "
-                        "(warp forward 9 us faster, step 60 - 90 us slower: a second active HW queue)")
     p.add_argument('--tunable_gemm', type=str2bool, default='True',
                    help='PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of each GEMM shape benchmarks '
                         'the rocBLAS / hipBLASLt candidates, as cudnn.benchmark does for the convs (~3 s once per host; fc1 forward '
@@ -166,10 +162,11 @@ class TrainStep(object):
         return staircase_lr(self.args.lr, self.global_step, self.decay_steps)
 
     # ---- whole-step hipGraph (torch.cuda.CUDAGraph on ROCm) -----------------------------------------------
-    # One training step is ~150 launches (convs, epilogues, the hot-path kernels, fused Adam) with ~10 % of the step
-    # spent in launch gaps on an otherwise GPU-bound stream.  Shapes are static, so the step is captured ONCE into a
-    # hipGraph over static input buffers and replayed: one graph launch per step, no per-kernel launch latency.  The
-    # library's kernels are captured like any other stream work (they only enqueue on the current stream).
+    # One training step is ~150 launches (convs, epilogues, the hot-path kernels, fused Adam).  The eager stream is already
+    # GPU-bound -- 5 492 of 5 512 us busy, 0.4 % in launch gaps (profiles/r04_step_breakdown.txt) -- so the graph buys no
+    # throughput at batch 64; it exists for small batches / slow hosts, where the ~150 launches per step outrun the GPU.
+    # Shapes are static, so the step is captured ONCE into a hipGraph over static input buffers and replayed: one graph
+    # launch per step.  The library's kernels are captured like any other stream work (they only enqueue on the stream).
     def _set_lr(self):
         lr = self.learning_rate()
         for g in self.opt.param_groups:
@@ -260,8 +257,7 @@ class TrainStep(object):
         self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
-                                h4p_offset=self.h4p_offset, zero_nonfinite_grad=self._zero_nonfinite(),
-                                prefetch_frame=getattr(self.args, 'prefetch_frame', None))
+                                h4p_offset=self.h4p_offset, zero_nonfinite_grad=self._zero_nonfinite())
         model.loss.backward()
         if self.averager is not None:
             self.averager.finish()
@@ -299,8 +295,7 @@ class TrainStep(object):
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
                                 graph_tail=getattr(self.args, 'graph_tail', False), h4p_offset=self.h4p_offset,
-                                zero_nonfinite_grad=self._zero_nonfinite(),
-                                prefetch_frame=getattr(self.args, 'prefetch_frame', None))
+                                zero_nonfinite_grad=self._zero_nonfinite())
         model.loss.backward()
         if self.averager is not None:
             self.averager.finish()

@@ -94,10 +94,7 @@ class VGGRegressor(nn.Module):
             x = self.bns[i](x)
         return x
 
-    def forward(self, model_input_nhwc, tail_hook=None, hook_before_fc1=False):
-        """`tail_hook` (optional callable): invoked once where the regressor has only small kernels left to enqueue -- after
-        fc1 (default) or before it -- so that the caller can start side-stream work that overlaps them (HomographyModel: the
-        Infinity-Cache prefetch of the frame the warp will sample).  It must not touch the activations."""
+    def forward(self, model_input_nhwc):
         # [B,P,P,2] NHWC -> NCHW-logical view with channels_last strides (no copy)
         x = model_input_nhwc.permute(0, 3, 1, 2)
         x = self._conv_pool(self._conv(x, 0), 1)
@@ -106,11 +103,7 @@ class VGGRegressor(nn.Module):
         x = self._conv(self._conv(x, 6), 7)
         x = F.dropout(x, self.dropout_p, self.training)
         x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)          # slim.flatten of NHWC
-        if tail_hook is not None and hook_before_fc1:
-            tail_hook()
         x = F.dropout(F.relu(self.fc1(x)), self.dropout_p, self.training)
-        if tail_hook is not None and not hook_before_fc1:
-            tail_hook()
         return self.fc2(x)
 
 
@@ -128,22 +121,10 @@ def reset_variables():
     _VARIABLE_SCOPE.clear()
 
 
-def prefetch_mode(v):
-    """'off' | 'dlt' | 'side' from a flag value (bool, '0' / '1' / '2', 'True' / 'False', or the names themselves)."""
-    if isinstance(v, bool):
-        return 'side' if v else 'off'
-    s = str(v).strip().lower()
-    if s in ('dlt', '2'):
-        return 'dlt'
-    if s in ('side', 'true', '1'):
-        return 'side'
-    return 'off'
-
-
 class HomographyModel(object):
     def __init__(self, args, I1, I2, I1_aug, I2_aug, I_aug, I_prime_aug, h4p, gt, patch_indices,
                  reuse_variables=None, model_index=0, net=None, fused_patch=False, solve_f64=False, graph_tail=False,
-                 h4p_offset=None, zero_nonfinite_grad=None, prefetch_frame=None):
+                 h4p_offset=None, zero_nonfinite_grad=None):
         self.params = args
         self.mode = args.mode
         self.is_training = True if self.mode == 'train' else False
@@ -164,19 +145,6 @@ class HomographyModel(object):
         self.fused_patch = fused_patch
         self.solve_f64 = solve_f64
         self.h4p_offset = h4p_offset        # [B,8] added to the regressor's output (bench / test hook; None = off)
-        # Infinity-Cache prefetch of I before the warp samples it -- a scheduling hint, bits unchanged.  Three modes:
-        #   'off'  (default)
-        #   'dlt'  rider blocks of the DLT-solve launch read I (ops.solve_dlt(prefetch=I) -> uh_dlt_forward_prefetch): no
-        #          second stream; the solve is latency-bound and leaves HBM idle
-        #   'side' (or True) a side stream forked after fc1 (ops.prefetch_frame): the warp forward drops from 27.5 to 18.8 us
-        #          but a second active HW queue costs the step 60 - 90 us (DESIGN.md 3.1 "Round 4", profiles/r04_prefetch_ab_*)
-        # None = UH_PREFETCH_FRAME ('0' / 'off', '1' / 'side', 'dlt'); UH_PREFETCH_AT=fc1 forks the side stream before fc1
-        import os
-        if prefetch_frame is None:
-            prefetch_frame = os.environ.get('UH_PREFETCH_FRAME', 'off')
-        self.prefetch_mode = prefetch_mode(prefetch_frame) if I_aug.is_cuda else 'off'
-        self.prefetch_frame = self.prefetch_mode == 'side'
-        self._prefetch_before_fc1 = os.environ.get('UH_PREFETCH_AT', 'fc2') == 'fc1'
         # A pair whose predicted corners are degenerate (collinear p2 -> singular 8x8 system -> theta = NaN) must not turn
         # every variable into NaN: in training its d loss / d pred_h4p is zeroed (UH_DLT_ZERO_NONFINITE_GRAD).  The reference
         # has no such guard (tf.matrix_solve raises on a singular system); default = on in train mode.
@@ -217,12 +185,7 @@ class HomographyModel(object):
         self._vgg()
 
     def _vgg(self):
-        if self.prefetch_frame and isinstance(self.net, VGGRegressor):
-            self.pred_h4p = self.net(self.model_input, tail_hook=lambda: ops.prefetch_frame(self.I),
-                                     hook_before_fc1=self._prefetch_before_fc1)
-        else:
-            self.prefetch_frame = False
-            self.pred_h4p = self.net(self.model_input)            # BATCH_SIZE x 8
+        self.pred_h4p = self.net(self.model_input)                # BATCH_SIZE x 8
         if self.h4p_offset is not None:
             self.pred_h4p = self.pred_h4p + self.h4p_offset
 
@@ -230,8 +193,6 @@ class HomographyModel(object):
     def solve_DLT(self):
         self._tail = None
         if self.graph_tail:
-            if self.prefetch_frame:
-                ops.join_prefetch(self.I.device)                   # the tail call below holds the warp
             with torch.set_grad_enabled(self._hot_grad):
                 self._tail = ops.photometric_tail(self.pts_1, self.pred_h4p, self.I, self.I2_aug, self.patch_indices,
                                                   self.params.patch_size, fused_patch=self.fused_patch, graph=True,
@@ -241,13 +202,10 @@ class HomographyModel(object):
         with torch.set_grad_enabled(self._hot_grad):
             self.H_mat, self._theta = ops.solve_dlt(self.pts_1, self.pred_h4p, self.params.img_w,
                                                     self.params.img_h, solve_f64=self.solve_f64,
-                                                    zero_nonfinite_grad=self.zero_nonfinite_grad,
-                                                    prefetch=self.I if self.prefetch_mode == 'dlt' else None)
+                                                    zero_nonfinite_grad=self.zero_nonfinite_grad)
 
     # ---- homography_model.py:252-269 ----------------------------------------------------------------
     def transform(self):
-        if self.prefetch_frame:
-            ops.join_prefetch(self.I.device)                       # the side-stream read of I has finished (or: wait for it)
         with torch.set_grad_enabled(self._hot_grad):
             self._transform()
 

@@ -51,37 +51,11 @@ def m_and_minv(img_w, img_h):
 
 
 # ------------------------------------------------------------------------------------------------
-# Infinity-Cache prefetch of the frame the warp is about to sample (uh_prefetch; DESIGN.md 3.1 "Round 4").  Inside the train
-# step `I` was last touched a whole conv stack ago: uh_warp_forward then costs 27 - 33 us instead of the 18 - 21 us it costs
-# on a frame that has just been read.  The read-and-discard pass is enqueued on a SIDE stream, forked from the current stream
-# where the regressor has only its small tail left to run (fc2, the DLT solve: kernels that leave HBM idle) and joined again
-# right before the warp.  The side stream and the two events live in the library (uh_prefetch_async / uh_prefetch_join).
-def prefetch_frame(t):
-    """Start reading `t` (a device tensor; its storage is not modified) into the memory-side cache on the library's side stream
-    (uh_prefetch_async: fork from the current stream by an event without the system-scope fence)."""
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise _lib.UHError('prefetch_frame: a tensor on the HIP device is required (got %s)' % getattr(t, 'device', type(t)))
-    nbytes = t.numel() * t.element_size() if t.is_contiguous() else 0
-    with torch.cuda.device(t.device):
-        _lib.check(_lib.load().uh_prefetch_async(C.c_void_p(t.data_ptr()), nbytes,
-                                                 C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)), 'uh_prefetch_async')
-
-
-def join_prefetch(device):
-    """Make the current stream wait for the prefetch started by prefetch_frame (no-op if there is none)."""
-    import os
-    if os.environ.get('UH_PREFETCH_JOIN', '1') == '0':          # experiment: fire and forget (the pass only reads)
-        return
-    with torch.cuda.device(device):
-        _lib.check(_lib.load().uh_prefetch_join(C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), 'uh_prefetch_join')
-
-
-# ------------------------------------------------------------------------------------------------
 class _DLTSolve(torch.autograd.Function):
     """pts1, h4p -> (H [B,3,3], theta [B,3,3] or None).  Gradient flows to h4p only (pts1 is data)."""
 
     @staticmethod
-    def forward(ctx, pts1, h4p, M, Minv, flags, prefetch=None):
+    def forward(ctx, pts1, h4p, M, Minv, flags):
         lib = _lib.load()
         pts1 = _f32(pts1, 'pts1').reshape(-1, 8)
         h4p = _f32(h4p, 'h4p').reshape(-1, 8)
@@ -94,14 +68,8 @@ class _DLTSolve(torch.autograd.Function):
         if M is not None:
             ctx.M_keep, Mh = _host9(M)
             ctx.Mi_keep, Mih = _host9(Minv)
-        if prefetch is not None and prefetch.is_cuda and prefetch.is_contiguous():
-            # rider blocks of the same launch read `prefetch` once (Infinity-Cache prefetch of the frame the warp samples next)
-            _lib.check(lib.uh_dlt_forward_prefetch(_ptr(pts1), _ptr(h4p), _ptr(H), _ptr(theta), Mh, Mih, B, flags,
-                                                   C.c_void_p(prefetch.data_ptr()), prefetch.numel() * prefetch.element_size(),
-                                                   _stream()), 'uh_dlt_forward_prefetch')
-        else:
-            _lib.check(lib.uh_dlt_forward(_ptr(pts1), _ptr(h4p), _ptr(H), _ptr(theta), Mh, Mih, B, flags, _stream()),
-                       'uh_dlt_forward')
+        _lib.check(lib.uh_dlt_forward(_ptr(pts1), _ptr(h4p), _ptr(H), _ptr(theta), Mh, Mih, B, flags, _stream()),
+                   'uh_dlt_forward')
         ctx.save_for_backward(pts1, h4p, H)
         ctx.set_materialize_grads(False)       # an unused output arrives as None, not as zeros
         ctx.flags = flags
@@ -136,21 +104,18 @@ class _DLTSolve(torch.autograd.Function):
             run((dH + Mit.t() @ dtheta @ Mt.t()).contiguous(), None)
         else:
             run(_f32(dH, 'dH'), None)
-        return None, dh4p, None, None, None, None
+        return None, dh4p, None, None, None
 
 
-def solve_dlt(pts1, h4p, img_w=None, img_h=None, solve_f64=False, zero_nonfinite_grad=False, prefetch=None):
-    """Tensor-DLT.  Returns H [B,3,3]; with img_w/img_h also theta = M^-1 H M (transform() :254).
-    `prefetch` (optional device tensor, e.g. the frame the warp will sample): read once by rider blocks of the same launch."""
+def solve_dlt(pts1, h4p, img_w=None, img_h=None, solve_f64=False, zero_nonfinite_grad=False):
+    """Tensor-DLT.  Returns H [B,3,3]; with img_w/img_h also theta = M^-1 H M (transform() :254)."""
     flags = _lib.UH_DLT_SOLVE_F64 if solve_f64 else _lib.UH_DLT_SOLVE_F32
     if zero_nonfinite_grad:          # a pair with degenerate predicted corners contributes no gradient (see the header)
         flags |= _lib.UH_DLT_ZERO_NONFINITE_GRAD
-    if prefetch is not None:
-        prefetch = prefetch.detach()
     if img_w is None:
-        return _DLTSolve.apply(pts1, h4p, None, None, flags, prefetch)
+        return _DLTSolve.apply(pts1, h4p, None, None, flags)
     M, Minv = m_and_minv(img_w, img_h)
-    return _DLTSolve.apply(pts1, h4p, M, Minv, flags, prefetch)
+    return _DLTSolve.apply(pts1, h4p, M, Minv, flags)
 
 
 # ------------------------------------------------------------------------------------------------
