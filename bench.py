@@ -78,7 +78,10 @@ def parse():
     ap.add_argument('--quality_texture', default='multiscale', choices=['smooth', 'multiscale'])
     ap.add_argument('--cpu_sample_pairs', type=int, default=64, help='CPU leg: batch size (default = the GPU batch)')
     ap.add_argument('--cpu_sample_steps', type=int, default=12, help='CPU leg: timed steps after one warm-up step')
-    ap.add_argument('--cpu_threads', type=int, default=32, help='host threads for the CPU leg (capped at nproc)')
+    ap.add_argument('--cpu_threads', type=int, default=32, help='host threads for the CPU leg (capped at nproc); 32 is the best of the '
+                    'sweep in profiles/r05_cpu_threads.txt')
+    ap.add_argument('--cpu_threads_sweep', default='', help='e.g. "8,32,128,256": time ONLY the CPU leg once per thread count on the '
+                    'default workload, print one JSON line per count, and exit (profiles/r05_cpu_threads.txt)')
     return ap.parse_args()
 
 
@@ -483,6 +486,17 @@ def main():
     tuned_gemms = uh_dist.tune_gemms() if args.tunable_gemm else False
     torch.manual_seed(1234)
 
+    if args.cpu_threads_sweep:
+        B = args.per_gpu_batch
+        batch = synthetic.make_batch(B, args.img_h, args.img_w, args.patch_size, args.rho, seed=100, device=device)
+        g = torch.Generator(device=device).manual_seed(4321)
+        off = batch['gt'] + 2.0 * torch.randn(B, 8, generator=g, device=device)
+        for n in (int(v) for v in args.cpu_threads_sweep.split(',') if v):
+            args.cpu_threads = n
+            r = cpu_baseline(args, batch, off)
+            print(json.dumps({'cpu_threads_requested': n, 'cores_used': r['cores'], 'host_cores': os.cpu_count(),
+                              'pairs_per_s': r['value'], 'sample': r['sample']}), flush=True)
+        return
     if args.only_points:
         out = {}
         if 'north_star' in args.only_points:
@@ -588,18 +602,11 @@ def main():
     exchange = None
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        av = step_fn.averager
-        # the exchange step on its own (collective, every rank takes part): per-bucket all-reduce time with nothing to hide
-        # under, next to the host time finish() spent blocked per step inside the timed region
-        try:
-            buckets = av.time_buckets(iters=5)
-        except Exception as e:                              # noqa: BLE001 -- an extra: must not lose the headline
-            buckets = {'error': '%s: %s' % (type(e).__name__, e)}
-        exchange = {'buckets': buckets, 'reduce_op': 'AVG' if av._avg_in_collective else 'SUM+div',
-                    'host_blocked_ms_per_step': round(av.exposed_wait_s / max(av.finishes, 1) * 1e3, 4),
-                    'note': 'bucket 0 = fc2+fc1 (issued first in backward, overlaps the conv backward), bucket 1 = conv; '
-                            'RCCL wait() only enqueues a stream dependency, so host_blocked is ~0 by construction: compare '
-                            'ms_per_step with the N=1 line to see what the exchange really costs'}
+        # the exchange step on its own and the step WITHOUT it (collective: every rank takes part) -- dist.exchange_report
+        def run_steps(n):
+            for _ in range(n):
+                step_fn(batch)
+        exchange = uh_dist.exchange_report(step_fn.averager, run_steps, float(tt.item()) / args.steps * 1e3)
     dt = float(tt.item())
     if rank != 0:
         if world > 1:

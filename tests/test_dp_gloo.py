@@ -57,6 +57,24 @@ def _worker(rank, world, port, q, backend='gloo'):
     tb = avg.time_buckets(iters=2)                 # the stand-alone exchange timing bench.py --gpus N reports
     assert len(tb) == 2 and all(b['ms'] > 0 and b['bytes'] > 0 for b in tb)
     assert avg.finishes == 2 and avg.exposed_wait_s >= 0.0
+    # the self-diagnosing part of bench.py --gpus N (dist.exchange_report): bucket timing with busbw against the xGMI figure,
+    # and the step WITHOUT the exchange -- every rank runs steps with the averager disabled (no collective is issued)
+    calls = []
+
+    def run_steps(n):
+        for _ in range(n):
+            avg.reset()
+            ((net(D.shard(X, rank, world)) - D.shard(Y, rank, world)) ** 2).mean().backward()
+            assert avg.enabled is False and avg._handles == []           # disabled: the hooks issued nothing
+            avg.finish()
+            calls.append(1)
+    fin_before = avg.finishes
+    rep = D.exchange_report(avg, run_steps, ms_per_step=5.0, steps_without=3, bucket_iters=2)
+    assert avg.enabled is True and len(calls) == 2 + 3 and avg.finishes == fin_before       # finish() is a no-op when disabled
+    assert rep['reduce_op'] == ('AVG' if backend == 'nccl' else 'SUM+div') and rep['steps_without_exchange'] == 3
+    assert rep['ms_per_step_no_exchange'] > 0 and abs(rep['exchange_cost_ms_per_step'] - (5.0 - rep['ms_per_step_no_exchange'])) < 2e-3
+    assert rep['xgmi'] == dict(rep['xgmi'], links_to_peers=1, GBs_per_link=153.0, peak_GBs=153.0)
+    assert all(abs(b['busbw_frac_of_xgmi'] - b['busbw_GBs'] / 153.0) < 1e-3 for b in rep['buckets'])
     q.put((rank, [[t.cpu().numpy() for t in r_] for r_ in res], float(vals[0])))
     torch.distributed.destroy_process_group()
 

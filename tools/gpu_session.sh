@@ -23,6 +23,12 @@
 #   coldv:V1,V2     cold-forward A/B/A/B of the shipped library against variants (batches 64, 128)
 #   power:LIBS:K    tools/power_ab.py: duration + socket power + energy per launch of kernel K (fwd | bwd) per library build
 #   trace:V         per-wave phase trace with the -DUH_WARP_TRACE variant V (tools/trace_waves.py)
+#   anatomy:V       what the in-step forward's fixed cost is made of (tools/trace_launch_anatomy.py, trace variant V): cold and warm
+#   ablate[:STEPS]  tools/train_from_disk.py, four arms (JPEG / PNG files x joint augmentation 0.5 / off), each tested with and
+#                   without the reference's disjoint test augmentation
+#   train_disk[:STEPS:PAIRS]  the reference's schedule (150 000 steps) FROM JPEG FILES with augmentation 0.5 (tools/train_from_disk.py)
+#   conv_relu_ab    aten::miopen_convolution_relu for the non-pooled convs (UH_CONV_FUSED_RELU=1) against the shipped epilogue, 3 x A/B
+#   cpu_threads     the CPU leg alone at 8 / 32 / 128 / 256 host threads
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 TAG=$1; shift
 COMMIT=${UH_COMMIT:-unknown}
@@ -73,6 +79,26 @@ for ST in "$@"; do
     trace)  UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py > gpurun_out/${TAG}_wave_trace_$A1.jsonl 2>gpurun_out/${TAG}_wave_trace.err
             UH_TRACE_BWD=1 UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_waves.py >> gpurun_out/${TAG}_wave_trace_$A1.jsonl 2>>gpurun_out/${TAG}_wave_trace.err
             cut -c1-1500 gpurun_out/${TAG}_wave_trace_$A1.jsonl ;;
+    anatomy) : > gpurun_out/${TAG}_launch_anatomy.jsonl
+            for WARM in 0 1; do UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_launch_anatomy.py --reps 5 --warm $WARM >> gpurun_out/${TAG}_launch_anatomy.jsonl 2>> gpurun_out/${TAG}_launch_anatomy.err; done
+            UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_launch_anatomy.py --reps 3 --shape 128,240,320,128,45 >> gpurun_out/${TAG}_launch_anatomy.jsonl 2>> gpurun_out/${TAG}_launch_anatomy.err
+            UH_LIB_PATH=$VDIR/libuh_$A1.so timeout 300 python tools/trace_launch_anatomy.py --reps 3 --shape 32,240,320,128,45 >> gpurun_out/${TAG}_launch_anatomy.jsonl 2>> gpurun_out/${TAG}_launch_anatomy.err
+            grep summary gpurun_out/${TAG}_launch_anatomy.jsonl | cut -c1-700; tail -3 gpurun_out/${TAG}_launch_anatomy.err ;;
+    ablate) timeout 1500 python tools/train_from_disk.py --arms jpg:0.5,jpg:0,png:0.5,png:0 --test_do_augment 0.5,0 --steps ${A1:-8000} --train_pairs 8192 --log_every 2000 > gpurun_out/${TAG}_train_from_disk_ablation.txt 2> gpurun_out/${TAG}_train_from_disk_ablation.err
+            grep -E "^\||dataset|trained|RESULT|free" gpurun_out/${TAG}_train_from_disk_ablation.txt | cut -c1-400; tail -3 gpurun_out/${TAG}_train_from_disk_ablation.err ;;
+    train_disk) timeout ${TRAIN_TIMEOUT:-1700} python tools/train_from_disk.py --arms jpg:0.5 --test_do_augment 0.5,0 --steps ${A1:-150000} --train_pairs ${A2:-65536} --log_every 10000 > gpurun_out/${TAG}_train_from_disk_reference_schedule.txt 2> gpurun_out/${TAG}_train_from_disk_reference_schedule.err
+            grep -E "^\||dataset|trained|RESULT|Average|ercentile|per-pair" gpurun_out/${TAG}_train_from_disk_reference_schedule.txt | cut -c1-500; grep "Train: step" gpurun_out/${TAG}_train_from_disk_reference_schedule.txt | tail -3 | cut -c1-300; tail -3 gpurun_out/${TAG}_train_from_disk_reference_schedule.err ;;
+    conv_relu_ab) : > gpurun_out/${TAG}_conv_relu_ab.jsonl
+            UH_CONV_FUSED_RELU=1 timeout 300 python -m pytest tests/test_gpu_model.py -m gpu -q --tb=short -k "conv_bias_relu" > gpurun_out/${TAG}_conv_relu_parity.log 2>&1; tail -3 gpurun_out/${TAG}_conv_relu_parity.log
+            for rep in 1 2 3; do for F in 0 1; do
+              UH_CONV_FUSED_RELU=$F timeout 400 python bench.py --quality 0 --cpu_baseline 0 --traffic 0 --north_star 0 --config4 0 --steps 60 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print(json.dumps({'miopen_convolution_relu': $F, 'rep': $rep, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step']}))" >> gpurun_out/${TAG}_conv_relu_ab.jsonl
+            done; done
+            ( cd /tmp && rm -rf /tmp/profcr_$TAG && UH_CONV_FUSED_RELU=1 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/profcr_$TAG -o cr --output-format csv -- $BENCH > /dev/null 2>&1 )
+            python tools/step_breakdown.py $(find /tmp/profcr_$TAG -name "*kernel_trace.csv" | head -1) 5 30 40 > gpurun_out/${TAG}_conv_relu_step_breakdown.txt 2>&1
+            cat gpurun_out/${TAG}_conv_relu_ab.jsonl; head -14 gpurun_out/${TAG}_conv_relu_step_breakdown.txt | cut -c1-200 ;;
+    cpu_threads) timeout 900 python bench.py --cpu_threads_sweep 8,32,64,128,256 > gpurun_out/${TAG}_cpu_threads.txt 2> gpurun_out/${TAG}_cpu_threads.err; cut -c1-200 gpurun_out/${TAG}_cpu_threads.txt ;;
     dp)     timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=short > gpurun_out/${TAG}_pytest_dp_product.log 2>&1; grep -E "world 2|passed|failed|Error|error" gpurun_out/${TAG}_pytest_dp_product.log | tail -12 ;;
     bench8) # `python bench.py --gpus 8` on ONE GPU: 8 gloo ranks (functional run of the N = 8 plumbing), wall time with the conv
             # find pass staggered (rank 0 first; default) and not, each from a cold MIOpen user db

@@ -15,7 +15,7 @@ if os.environ.get('UH_IDENTITY_THETA'):
     theta = torch.eye(3, device=dev).reshape(1, 9).repeat(B, 1).contiguous()
 lib = _lib.load()
 nw = B * ((W + 63) // 64) * ((H + 15) // 16) * 4
-tr = torch.zeros(nw * 8, dtype=torch.int64, device=dev)
+tr = torch.zeros(nw * 16, dtype=torch.int64, device=dev)      # UH_TRACE_STRIDE
 out = torch.empty_like(U)
 p = lambda t: C.c_void_p(t.data_ptr())
 BWD = bool(os.environ.get('UH_TRACE_BWD'))        # trace the backward (dense dOut) instead of the forward
@@ -31,7 +31,7 @@ torch.cuda.synchronize()
 assert C.CDLL(_lib.LIB_PATH).uh_debug_set_trace(p(tr)) == 0
 run()
 torch.cuda.synchronize()
-t = tr.cpu().numpy().reshape(nw, 8).astype(np.int64)
+t = tr.cpu().numpy().reshape(nw, 16).astype(np.int64)
 t = t[(t[:, 0] > 0) & (t[:, 7] > 0)]
 span = t[:, 7].max() - t[:, 0].min()
 life = t[:, 7] - t[:, 0]

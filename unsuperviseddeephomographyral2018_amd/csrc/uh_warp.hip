@@ -232,14 +232,23 @@ __device__ __forceinline__ void global_quad(__amdgpu_buffer_rsrc_t rin, unsigned
 // Developer instrumentation (tools/trace_waves.py; never in the shipped library): lane 0 of every wave (forward, and
 // the backward with UH_TRACE_BWD=1; s_memtime orders with memory waits, not with VALU work, so the compute phases are
 // approximate) records
-// s_memtime at its phase boundaries and the path it took.  trace[w*8 + ..] = t0 entry, t1 decision made, t2 loads /
-// DMA issued, t3 data landed, t4 stores issued, [5] path (0 A, 1 B, 2 C1, 3 C2), [6] DMA instructions.
+// s_memtime at its phase boundaries and the path it took.  trace[w*16 + ..] = t0 entry, t1 decision made, t2 loads /
+// DMA issued, t3 data landed, t4 stores issued, [5] path (0 A, 1 B, 2 C1, 3 C2), [6] DMA instructions, [7] t_end;
+// [8] / [9] s_memrealtime (the chip-wide 100 MHz counter: comparable ACROSS XCDs, which the per-XCD shader clock behind
+// s_memtime is not) at entry / end, [10] XCC_ID, [11] HW_ID (CU / SE of the wave).
 __device__ unsigned long long* g_trace = nullptr;
+#define UH_TRACE_STRIDE 16
 #define UH_TR(i) do { if (trp) trp[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define UH_TRV(i, v) do { if (trp) trp[i] = (unsigned long long)(v); } while (0)
+#define UH_TR_ENTRY() do { if (trp) { trp[8] = __builtin_amdgcn_s_memrealtime(); \
+                                      trp[10] = (unsigned long long)__builtin_amdgcn_s_getreg(6164);  /* hwreg(HW_REG_XCC_ID, 0, 4) */ \
+                                      trp[11] = (unsigned long long)__builtin_amdgcn_s_getreg(63492); /* hwreg(HW_REG_HW_ID, 0, 32) */ } } while (0)
+#define UH_TR_EXIT() do { if (trp) trp[9] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define UH_TR(i) do {} while (0)
 #define UH_TRV(i, v) do {} while (0)
+#define UH_TR_ENTRY() do {} while (0)
+#define UH_TR_EXIT() do {} while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -260,9 +269,9 @@ __global__ __launch_bounds__(256, ((C == 4 || COND) ? UH_WARP_FWD_MINW - 1 : UH_
     const int row0 = ty * TH + (lane / TW);                              // this lane's first row
     if ((tx * NWAVE + wave) * TW >= ow) return;                          // whole wave outside (wave-uniform)
 #ifdef UH_WARP_TRACE
-    unsigned long long* trp = (g_trace && lane == 0) ? g_trace + ((size_t)v * NWAVE + wave) * 8 : nullptr;
+    unsigned long long* trp = (g_trace && lane == 0) ? g_trace + ((size_t)v * NWAVE + wave) * UH_TRACE_STRIDE : nullptr;
 #endif
-    UH_TR(0);
+    UH_TR_ENTRY(); UH_TR(0);
     const Theta th = load_theta(theta, b);
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(U + (size_t)b * H * W * C, (unsigned)(H * W * C * 4));
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(out + (size_t)b * oh * ow * C, (unsigned)(oh * ow * C * 4));
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(256, ((C == 4 || COND) ? UH_WARP_FWD_MINW - 1 : UH_
     }
 #ifdef UH_WARP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // stores acknowledged
-    UH_TR(7);
+    UH_TR(7); UH_TR_EXIT();
 #endif
     if (COND) {
         cnt = wave_sum(cnt);
@@ -636,9 +645,9 @@ __global__ __launch_bounds__(256, (WANT_DU ? 3 : (C == 4 ? UH_WARP_BWD_MINW - 1 
     const int col = (tx * NWAVE + wave) * TW + (lane & (TW - 1));
     const int row0 = ty * TH_B + (lane / TW);                              // this lane's first row
 #ifdef UH_WARP_TRACE
-    unsigned long long* trp = (g_trace && lane == 0) ? g_trace + ((size_t)v * NWAVE + wave) * 8 : nullptr;
+    unsigned long long* trp = (g_trace && lane == 0) ? g_trace + ((size_t)v * NWAVE + wave) * UH_TRACE_STRIDE : nullptr;
 #endif
-    UH_TR(0);
+    UH_TR_ENTRY(); UH_TR(0);
     float acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = 0.f;
@@ -862,7 +871,7 @@ __global__ __launch_bounds__(256, (WANT_DU ? 3 : (C == 4 ? UH_WARP_BWD_MINW - 1 
             pa.confirmed[v] = nc;
         }
     }
-    UH_TR(7);
+    UH_TR(7); UH_TR_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------

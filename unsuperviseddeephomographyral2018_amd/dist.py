@@ -78,13 +78,28 @@ def tune_gemms(max_ms_per_solution=15, max_iterations=20, filename=None):
     fc1 is a skinny GEMM (batch x 32768 x 1024: 134 MB of weights for 64 rows); the library heuristic's pick runs the forward
     in 142 us where the weights could stream in ~25 (profiles/r04_step_breakdown.txt).  With TunableOp on, the first call of
     each GEMM shape benchmarks the rocBLAS / hipBLASLt candidates and keeps the fastest; results are cached in `filename`
-    (default /tmp/uh_tunableop[_r<local rank>_]<device>.csv, validated against the library versions), so later processes on the same host
-    skip the search.  Returns True when TunableOp was switched on."""
+    (default: <per-user cache dir>/tunableop[_r<local rank>_]<device>.csv -- ~/.cache/uh_hotpath, or $TMPDIR/uh_hotpath_uid<uid>
+    when the home directory is not writable; never a world-shared path another user could have planted -- validated against the
+    library versions), so later processes of the same user on the same host skip the search.  Returns True when TunableOp was
+    switched on.
+    Reproducibility: the pick is timing-dependent, so two runs (or two ranks) may choose different GEMM kernels for the same shape
+    -- results then differ in the last bits (reduction order), like MIOpen's find mode does for the convs; test mode does not
+    tune (it uses the library heuristic).  --tunable_gemm False gives the library heuristic everywhere."""
     try:
         import torch.cuda.tunable as tun
         # one results file per (local rank, device): ranks that share a GPU (gloo dry runs) must not write the same file at exit
         lr = os.environ.get('LOCAL_RANK')
-        tun.set_filename(filename or ('/tmp/uh_tunableop%s.csv' % ('_r' + lr + '_' if lr is not None else '')), insert_device_ordinal=True)
+        if filename is None:
+            d = os.path.join(os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache'), 'uh_hotpath')
+            try:
+                os.makedirs(d, mode=0o700, exist_ok=True)
+                if not os.access(d, os.W_OK):
+                    raise OSError(d)
+            except OSError:
+                d = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'uh_hotpath_uid%d' % os.getuid())
+                os.makedirs(d, mode=0o700, exist_ok=True)
+            filename = os.path.join(d, 'tunableop%s.csv' % ('_r' + lr + '_' if lr is not None else ''))
+        tun.set_filename(filename, insert_device_ordinal=True)
         tun.set_max_tuning_duration(int(max_ms_per_solution))
         tun.set_max_tuning_iterations(int(max_iterations))
         tun.enable(True)
@@ -170,8 +185,9 @@ class GradAverager(object):
                                        'optimizer.zero_grad(set_to_none=False) or GradAverager.reset() only')
 
     def finish(self):
-        """Call after backward, before optimizer.step(): wait for the all-reduces and divide by world."""
-        if self.world > 1:
+        """Call after backward, before optimizer.step(): wait for the all-reduces and divide by world.  With `enabled` False
+        (no collective was issued) it does nothing: every rank keeps its own tower's gradient."""
+        if self.world > 1 and self.enabled:
             import time
             for b in self.buckets:
                 if b['pending'] != 0:          # a parameter received no gradient: reduce it now
@@ -212,6 +228,60 @@ class GradAverager(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+XGMI_LINK_GBS = 153.0        # per direction per link, 7 links per GPU on an 8-GPU MI355X node
+
+
+def exchange_report(averager, run_steps, ms_per_step, steps_without=10, bucket_iters=5):
+    """What the gradient exchange costs, readable from ONE line of the first real multi-GPU run.  Collective:
+    every rank must call it, after the timed region.
+      buckets                    stand-alone all-reduce time per bucket (nothing to hide under), algbw / busbw, and busbw as a
+                                 fraction of the xGMI bandwidth a rank can use towards its world - 1 peers (links x 153 GB/s)
+      ms_per_step_no_exchange    `steps_without` more steps with the averager DISABLED on every rank (each tower keeps its own
+                                 gradient; barrier + device sync either side, MAX over ranks) -- the step without the exchange
+      exchange_cost_ms_per_step  ms_per_step - ms_per_step_no_exchange: the un-hidden part of the exchange PLUS what the RCCL
+                                 kernels take from the conv backward they overlap (CU / HBM contention) -- the number
+                                 host_blocked_ms_per_step cannot show on RCCL, whose wait() only enqueues a stream dependency
+    run_steps(n) runs n training steps of the caller's TrainStep."""
+    import time
+    world = averager.world
+    out = {'reduce_op': 'AVG' if averager._avg_in_collective else 'SUM+div',
+           'host_blocked_ms_per_step': round(averager.exposed_wait_s / max(averager.finishes, 1) * 1e3, 4)}
+    try:
+        buckets = averager.time_buckets(iters=bucket_iters)
+        peak = max(world - 1, 1) * XGMI_LINK_GBS
+        for b in buckets:
+            b['busbw_frac_of_xgmi'] = round(b['busbw_GBs'] / peak, 4)
+        out['buckets'] = buckets
+        out['xgmi'] = {'links_to_peers': max(world - 1, 1), 'GBs_per_link': XGMI_LINK_GBS, 'peak_GBs': peak,
+                       'note': 'busbw = algbw * 2 (n - 1) / n; point-to-point xGMI: a rank reaches each of its n - 1 peers over one '
+                               'link, so a direct all-reduce is bound by (n - 1) x 153 GB/s per direction'}
+    except Exception as e:                                  # noqa: BLE001 -- a diagnostic: must not lose the headline
+        out['buckets'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    dev = averager.buckets[0]['flat'].device if averager.buckets else torch.device('cpu')
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == 'cuda' else (lambda: None)
+    try:
+        averager.enabled = False
+        run_steps(2)                                        # settle (the allocator sees a step without the collectives)
+        sync(); dist.barrier(); sync()
+        t0 = time.perf_counter()
+        run_steps(steps_without)
+        sync(); dist.barrier(); sync()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms_wo = float(tt.item()) / steps_without * 1e3
+        out['ms_per_step_no_exchange'] = round(ms_wo, 3)
+        out['exchange_cost_ms_per_step'] = round(ms_per_step - ms_wo, 3)
+        out['steps_without_exchange'] = steps_without
+    except Exception as e:                                  # noqa: BLE001
+        out['ms_per_step_no_exchange'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    finally:
+        averager.enabled = True
+    out['note'] = ('bucket 0 = fc2+fc1 (issued first in backward, overlaps the conv backward), bucket 1 = conv; RCCL wait() only '
+                   'enqueues a stream dependency, so host_blocked is ~0 by construction: exchange_cost_ms_per_step is the figure '
+                   'that shows what the exchange really costs (un-hidden time + contention with the conv backward)')
+    return out
 
 
 def all_reduce_mean_scalars(values, world):

@@ -481,7 +481,7 @@ class TestHomography(object):
             disk = loader.stream()             # shuffle=False: consecutive batches walk the list in order, wrapping
         steps_per_epoch = int(np.ceil(num_test_data / a.batch_size))
         num_steps = 3 * steps_per_epoch                                   # (:400-401)
-        per_pair, total_fail, total_bounded = [], 0.0, 0.0
+        per_pair, per_step, total_fail, total_bounded = [], [], 0.0, 0.0
         was_training = self.net.training
         with torch.no_grad():
             for step in range(num_steps):
@@ -490,22 +490,46 @@ class TestHomography(object):
                     device=self.device, kind=getattr(a, 'texture', 'smooth'))
                 m = HomographyModel(self.params, *synthetic.model_args(batch), reuse_variables=True, net=self.net,
                                     solve_f64=a.solve_f64)
-                total_bounded += float(m.bounded_h_loss)
+                per_step.append(float(m.bounded_h_loss))                   # h_losses_array.append(h_loss_value) (:537)
+                total_bounded += per_step[-1]
                 total_fail += float(m.num_fail)
                 per_pair.append(torch.sqrt(torch.mean((m.pred_h4p - m.gt) ** 2, dim=1)).cpu())
         self.net.train(was_training)
+        if disk is not None:
+            disk.close()
         per_pair = torch.cat(per_pair).numpy()
         res = {
             'mean_corner_error': total_bounded / num_steps,
             'fail_percent': 100.0 * total_fail / (num_steps * a.batch_size),
-            'percentiles': {q: float(np.percentile(per_pair, q)) for q in (20, 30, 50, 60, 80, 100)},   # (:577-579)
+            # the REFERENCE's printout (:577-579 -> utils.find_percentile, utils.py:655-672): [mean, std] of the sorted per-STEP
+            # bounded h_loss values (one per test batch) in the intervals 0-30 %, 30-60 %, 60-100 %
+            'reference_percentile_intervals': find_percentile(per_step),
+            # ... and two statistics the reference does not print (per PAIR, unbounded corner RMSE): point percentiles, and the
+            # same three intervals -- the form the paper's bar charts use
+            'percentiles': {q: float(np.percentile(per_pair, q)) for q in (20, 30, 50, 60, 80, 100)},
+            'per_pair_intervals': find_percentile(per_pair),
             'num_pairs': int(per_pair.size),
         }
-        print('====> Result for RHO:', a.rho, ' loss ', a.loss_type)
+        print('====> Result for RHO:', a.rho, ' loss ', a.loss_type, ' noise ', getattr(a, 'do_augment', None) if disk is not None else 0.0)
         print('|Average error: %.4f |Fail percent: %.3f' % (res['mean_corner_error'], res['fail_percent']))
-        print('===> Percentile Values (per-pair corner RMSE, px): ' + ', '.join(
-            '%d%%: %.3f' % (q, v) for q, v in sorted(res['percentiles'].items())) + '  over %d pairs' % res['num_pairs'])
+        print('===> Percentile Values (the reference\'s find_percentile: [mean, std] of the per-batch h_loss in the sorted intervals '
+              '0-30 %%, 30-60 %%, 60-100 %%): %s' % np.round(np.array(res['reference_percentile_intervals']), 3).tolist())
+        print('===> per-pair corner RMSE (px; not a reference printout): point percentiles ' + ', '.join(
+            '%d%%: %.3f' % (q, v) for q, v in sorted(res['percentiles'].items())) + '; intervals 0-30/30-60/60-100 %% [mean, std]: %s'
+            % np.round(np.array(res['per_pair_intervals']), 3).tolist() + '  over %d pairs' % res['num_pairs'])
         return res
+
+
+def find_percentile(x, tops_list=(0.3, 0.6, 1)):
+    """utils.find_percentile (utils/utils.py:655-672): sort x; [mean, std] of the intervals [0, 30 %), [30 %, 60 %), [60 %, 100 %)."""
+    xs = np.sort(np.asarray(x, dtype=np.float64))
+    out, start = [], 0
+    for t in tops_list:
+        stop = int(t * len(xs))
+        iv = xs[start:stop]
+        out.append([float(np.mean(iv)) if iv.size else float('nan'), float(np.std(iv)) if iv.size else float('nan')])
+        start = stop
+    return out
 
 
 def main(argv=None):
