@@ -333,6 +333,19 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return base + slot;
 }
 
+#ifdef UH_XCD_CHUNK_ROWS
+// Round-5 A/B (tools/variants.sh, never defined in the shipped build): instead of ONE contiguous range per XCD -- whole images,
+// 8 of them at batch 64, whose path mixes differ, so that the XCDs finish 5 - 7 us apart (profiles/r05_launch_anatomy.jsonl) --
+// XCD x takes the chunks x, x + 8, x + 16, ... of `chunk` consecutive virtual ids (UH_XCD_CHUNK_ROWS tile rows of one image):
+// every XCD sees a slice of every image.  Bijective when 8 * chunk divides the grid; otherwise the contiguous map.
+__device__ __forceinline__ unsigned xcd_remap_chunked(unsigned bid, unsigned nblk, unsigned chunk) {
+    if (chunk == 0u || nblk % (8u * chunk) != 0u) return xcd_remap(bid, nblk);
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const unsigned c = slot / chunk, o = slot - c * chunk;
+    return (c * 8u + xcd) * chunk + o;
+}
+#endif
+
 // ---- wave / block reductions -------------------------------------------------------------------
 // f32: DPP butterfly inside each row of 16 lanes, then row_bcast15 / row_bcast31 (gfx9 DPP controls) --
 // six v_add_f32_dpp, no LDS traffic (a __shfl_down tree is six ds_bpermute_b32 round trips).  The total is
