@@ -184,17 +184,31 @@ def regressor_flops(P):
 
 
 def reference_schedule_result():
-    """The committed result of the ONE run at the reference's own schedule (150 000 steps, lr 1e-4; tools/train_reference_schedule.sh)
-    -- read from profiles/, NOT measured in this run (it takes 14 GPU-minutes)."""
+    """The committed results of the runs at the reference's own schedule (150 000 steps, lr 1e-4) -- read from profiles/, NOT
+    measured in this run (14 GPU-minutes each): the clean in-HBM pool (tools/train_reference_schedule.sh) and, since round 5, the
+    reference's real input route -- JPEG files + joint augmentation through Dataloader / uh_prepare_inputs -- tested with and
+    without the reference's disjoint test augmentation (tools/train_from_disk.py)."""
     import re
+    out = None
     f = os.path.join(ROOT, 'profiles', 'r04_train_reference_schedule.txt')
     try:
         txt = open(f).read()
         m = re.search(r'Average error: ([0-9.]+) \|Fail percent: ([0-9.]+)', txt)
-        return {'mean_corner_error_px': float(m.group(1)), 'fail_percent': float(m.group(2)), 'train_steps': 150000,
-                'file': 'profiles/r04_train_reference_schedule.txt', 'note': 'read from the committed log, not measured in this run'}
+        out = {'mean_corner_error_px': float(m.group(1)), 'fail_percent': float(m.group(2)), 'train_steps': 150000,
+               'file': 'profiles/r04_train_reference_schedule.txt', 'note': 'read from the committed log, not measured in this run',
+               'data': 'clean in-HBM pool of 65 536 synthetic pairs, augment_list = [normalize]'}
     except Exception:
         return None
+    f2 = os.path.join(ROOT, 'profiles', 'r05_train_from_disk_reference_schedule.txt')
+    try:
+        rows = [json.loads(l[len('RESULT '):]) for l in open(f2) if l.startswith('RESULT ')]
+        out['from_jpeg_files_with_augmentation'] = {
+            'file': 'profiles/r05_train_from_disk_reference_schedule.txt', 'note': 'read from the committed log, not measured in this run',
+            'results': [{k: r[k] for k in ('files', 'train_do_augment', 'test_do_augment', 'steps', 'train_pairs', 'mean_corner_error_px',
+                                           'fail_percent', 'per_pair_median_px')} for r in rows]}
+    except Exception:
+        pass
+    return out
 
 
 def tile_paths(theta, H, W, lds_bytes=5120, tile=16):

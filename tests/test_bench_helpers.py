@@ -131,6 +131,7 @@ def test_timed_steps_stats_blocks(tmp_path):
     lines = r.stdout.splitlines()
     assert lines[0].startswith('# _fingerprint: ' + build._fingerprint())
     assert 'steps averaged: %d' % K in lines[1] and 'sum of kernel durations per step 38.0 us' in lines[1]
+    assert 'wall per step 38.3 us' in lines[1]                         # 3 kernels + 3 x 100 ns gaps: not the read-back pause after the timed region
     assert any('27.0 us/step' in l and 'warp_forward' in l for l in lines) and not any('naive_conv' in l for l in lines)
 
 

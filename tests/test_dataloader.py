@@ -339,3 +339,65 @@ def test_worker_errors_raise_instead_of_deadlocking(tmp_path):
     b = next(it)
     assert np.array_equal(b['I8'].numpy(), I[b['ids']])
     it.close()
+
+
+def test_mode_picks_joint_or_disjoint_and_the_apply_rule_is_u_gt_one_minus_p(tmp_path, monkeypatch):
+    """VERDICT r4 item 1c.  The reference augments a pair iff  u > 1 - do_augment,  u ~ U[0,1) drawn per pair
+    (dataloader.py:160,166-169): JOINTLY (one draw of gamma / brightness / colour for both images) when mode == 'train',
+    DISJOINTLY (independent draws) otherwise -- the test mode's "noise".  Pinned at three levels: the sampler against a replay of
+    its own random stream; Dataloader._finish (what uh_prepare_inputs receives, captured on the CPU); and the test driver's
+    choice of mode."""
+    from types import SimpleNamespace
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    from unsuperviseddeephomographyral2018_amd import homography_CNN_synthetic as drv
+    # (1) the rule, replayed: the sampler draws gamma [B,2,1], brightness [B,2,1], colour [B,2,3], then u [B]
+    for p in (0.0, 0.25, 0.5, 1.0):
+        g = torch.Generator().manual_seed(11)
+        a = dl.sample_augmentation(512, 'test', p, g)
+        r = torch.Generator().manual_seed(11)
+        for shape in ((512, 2, 1), (512, 2, 1), (512, 2, 3)):
+            torch.rand(*shape, generator=r)
+        u = torch.rand(512, generator=r)
+        applied = ~(a == 1.0).all(dim=2).all(dim=1)
+        assert torch.equal(applied, u > (1.0 - p)), p                      # do_augment > (1 - self.params.do_augment)  (:166,169)
+        assert applied.float().mean().item() == pytest.approx(p, abs=0.07)
+    # (2) what reaches the kernel: joint in 'train', disjoint in 'test' -- through Dataloader._finish, no GPU needed
+    rs = np.random.RandomState(3)
+    N, H, W, P = 16, 24, 32, 8
+    I = _frames(rs, N, H, W); Ip = _frames(rs, N, H, W)
+    pts1 = np.tile(np.array([[4, 4, 12, 4, 12, 12, 4, 12]], np.float32), (N, 1)); gt = np.zeros((N, 8), np.float32)
+    ff, fp, fg = dl.write_dataset(str(tmp_path) + '/', I, Ip, pts1, gt)
+    seen = {}
+
+    def fake_prepare(I8, Ip8, p1, patch, aug, mean, std):
+        seen['aug'] = None if aug is None else aug.clone()
+        return {}
+    monkeypatch.setattr(dl, 'prepare_inputs', fake_prepare)
+    for mode in ('train', 'test'):
+        prm = dl.dataloader_params(data_path=str(tmp_path) + '/', filenames_file=ff, pts1_file=fp, gt_file=fg, mode=mode,
+                                   batch_size=N, img_h=H, img_w=W, patch_size=P, augment_list=['normalize'], do_augment=1.0)
+        next(dl.Dataloader(prm, shuffle=False, device='cpu', seed=5).stream())
+        aug = seen['aug']
+        assert aug.shape == (N, 2, 5) and not (aug == 1.0).all()
+        same = bool(torch.equal(aug[:, 0], aug[:, 1]))
+        assert same == (mode == 'train'), mode                               # :166 joint_augment_image_pair / :169 disjoint_...
+    prm0 = prm._replace(do_augment=0.0)
+    next(dl.Dataloader(prm0, shuffle=False, device='cpu').stream())
+    assert seen['aug'] is None                                               # do_augment 0: the kernel's un-augmented instantiation
+    # (3) the test driver asks for mode 'test' (disjoint), unshuffled, with the user's do_augment (homography_CNN_synthetic.py:138-148)
+    got = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_loader(prm_, **kw):
+        got['prm'], got['kw'] = prm_, kw
+        raise Stop
+    monkeypatch.setattr(drv.uh_data, 'Dataloader', fake_loader)
+    args = drv.build_parser().parse_args(['--mode', 'test', '--data_path', str(tmp_path) + '/', '--test_filenames_file', ff,
+                                          '--test_pts1_file', fp, '--test_gt_file', fg, '--do_augment', '0.5', '--batch_size', '4'])
+    t = drv.TestHomography(args, step_fn=SimpleNamespace(net=torch.nn.Linear(1, 1)))
+    with pytest.raises(Stop):
+        t.run()
+    assert got['prm'].mode == 'test' and got['prm'].do_augment == 0.5 and got['kw']['shuffle'] is False
+    assert got['prm'].filenames_file == ff and got['prm'].augment_list == ['normalize']
