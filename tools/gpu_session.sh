@@ -27,7 +27,7 @@
 #   ablate[:STEPS]  tools/train_from_disk.py, four arms (JPEG / PNG files x joint augmentation 0.5 / off), each tested with and
 #                   without the reference's disjoint test augmentation
 #   train_disk[:STEPS:PAIRS]  the reference's schedule (150 000 steps) FROM JPEG FILES with augmentation 0.5 (tools/train_from_disk.py)
-#   conv_relu_ab    aten::miopen_convolution_relu for the non-pooled convs (UH_CONV_FUSED_RELU=1) against the shipped epilogue, 3 x A/B
+#   conv_relu_probe aten::miopen_convolution_relu per conv shape against conv + the shipped bias/ReLU pass (tools/conv_relu_probe.py)
 #   cpu_threads     the CPU leg alone at 8 / 32 / 128 / 256 host threads
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 TAG=$1; shift
@@ -88,16 +88,8 @@ for ST in "$@"; do
             grep -E "^\||dataset|trained|RESULT|free" gpurun_out/${TAG}_train_from_disk_ablation.txt | cut -c1-400; tail -3 gpurun_out/${TAG}_train_from_disk_ablation.err ;;
     train_disk) timeout ${TRAIN_TIMEOUT:-1700} python tools/train_from_disk.py --arms jpg:0.5 --test_do_augment 0.5,0 --steps ${A1:-150000} --train_pairs ${A2:-65536} --log_every 10000 > gpurun_out/${TAG}_train_from_disk_reference_schedule.txt 2> gpurun_out/${TAG}_train_from_disk_reference_schedule.err
             grep -E "^\||dataset|trained|RESULT|Average|ercentile|per-pair" gpurun_out/${TAG}_train_from_disk_reference_schedule.txt | cut -c1-500; grep "Train: step" gpurun_out/${TAG}_train_from_disk_reference_schedule.txt | tail -3 | cut -c1-300; tail -3 gpurun_out/${TAG}_train_from_disk_reference_schedule.err ;;
-    conv_relu_ab) : > gpurun_out/${TAG}_conv_relu_ab.jsonl
-            UH_CONV_FUSED_RELU=1 timeout 300 python -m pytest tests/test_gpu_model.py -m gpu -q --tb=short -k "conv_bias_relu" > gpurun_out/${TAG}_conv_relu_parity.log 2>&1; tail -3 gpurun_out/${TAG}_conv_relu_parity.log
-            for rep in 1 2 3; do for F in 0 1; do
-              UH_CONV_FUSED_RELU=$F timeout 400 python bench.py --quality 0 --cpu_baseline 0 --traffic 0 --north_star 0 --config4 0 --steps 60 2>gpurun_out/${TAG}_conv_relu_bench_$F.err | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print(json.dumps({'miopen_convolution_relu': $F, 'rep': $rep, 'pairs_s': d['value'], 'ms_per_step': d['ms_per_step']}))" >> gpurun_out/${TAG}_conv_relu_ab.jsonl
-            done; done
-            ( cd /tmp && rm -rf /tmp/profcr_$TAG && UH_CONV_FUSED_RELU=1 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/profcr_$TAG -o cr --output-format csv -- $BENCH > /dev/null 2>&1 )
-            python tools/step_breakdown.py $(find /tmp/profcr_$TAG -name "*kernel_trace.csv" | head -1) 5 30 40 > gpurun_out/${TAG}_conv_relu_step_breakdown.txt 2>&1
-            cat gpurun_out/${TAG}_conv_relu_ab.jsonl; head -14 gpurun_out/${TAG}_conv_relu_step_breakdown.txt | cut -c1-200; grep -v "^$" gpurun_out/${TAG}_conv_relu_bench_1.err | tail -8 | cut -c1-300 ;;
+    conv_relu_probe) ( cd /tmp && rm -rf /tmp/pcr_$TAG && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pcr_$TAG -o cr --output-format csv -- python /root/repo/tools/conv_relu_probe.py > /root/repo/gpurun_out/${TAG}_conv_relu_probe.jsonl 2> /root/repo/gpurun_out/${TAG}_conv_relu_probe.err )
+            cp $(find /tmp/pcr_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_conv_relu_probe_kernel_stats.csv 2>/dev/null; cut -c1-400 gpurun_out/${TAG}_conv_relu_probe.jsonl ;;
     cpu_threads) timeout 900 python bench.py --cpu_threads_sweep 8,32,64,128,256 > gpurun_out/${TAG}_cpu_threads.txt 2> gpurun_out/${TAG}_cpu_threads.err; cut -c1-200 gpurun_out/${TAG}_cpu_threads.txt ;;
     dp)     timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=short > gpurun_out/${TAG}_pytest_dp_product.log 2>&1; grep -E "world 2|passed|failed|Error|error" gpurun_out/${TAG}_pytest_dp_product.log | tail -12 ;;
     bench8) # `python bench.py --gpus 8` on ONE GPU: 8 gloo ranks (functional run of the N = 8 plumbing), wall time with the conv

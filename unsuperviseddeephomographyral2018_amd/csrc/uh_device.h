@@ -324,6 +324,9 @@ __device__ __forceinline__ float blend4(float wa, float wb, float wc, float wd, 
 // The dispatcher places block b on XCD b % 8.  Give every XCD one CONTIGUOUS range of virtual block
 // ids so that the tiles of one image (which share source rows) meet in one 4 MiB L2.  Bijective for
 // any grid size (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").  Speed only.
+// (Round 5 measured the price of this choice -- the XCDs finish a batch-64 launch 5 - 7 us apart because whole images differ in
+// cost -- and the alternative, chunks of 1 / 3 / 15 tile rows dealt round-robin to the XCDs: +0.5 ... +2.7 us warm (lost L2
+// sharing), no gain cold beyond the session noise: profiles/r05_cold_forward_xcd_chunk_variants.jsonl.  Contiguous stays.)
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 #ifdef UH_NO_XCD_REMAP            // developer A/B switch only (tools/variants.sh)
     return bid;
@@ -332,19 +335,6 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
     return base + slot;
 }
-
-#ifdef UH_XCD_CHUNK_ROWS
-// Round-5 A/B (tools/variants.sh, never defined in the shipped build): instead of ONE contiguous range per XCD -- whole images,
-// 8 of them at batch 64, whose path mixes differ, so that the XCDs finish 5 - 7 us apart (profiles/r05_launch_anatomy.jsonl) --
-// XCD x takes the chunks x, x + 8, x + 16, ... of `chunk` consecutive virtual ids (UH_XCD_CHUNK_ROWS tile rows of one image):
-// every XCD sees a slice of every image.  Bijective when 8 * chunk divides the grid; otherwise the contiguous map.
-__device__ __forceinline__ unsigned xcd_remap_chunked(unsigned bid, unsigned nblk, unsigned chunk) {
-    if (chunk == 0u || nblk % (8u * chunk) != 0u) return xcd_remap(bid, nblk);
-    const unsigned xcd = bid & 7u, slot = bid >> 3;
-    const unsigned c = slot / chunk, o = slot - c * chunk;
-    return (c * 8u + xcd) * chunk + o;
-}
-#endif
 
 // ---- wave / block reductions -------------------------------------------------------------------
 // f32: DPP butterfly inside each row of 16 lanes, then row_bcast15 / row_bcast31 (gfx9 DPP controls) --

@@ -262,11 +262,7 @@ __global__ __launch_bounds__(256, ((C == 4 || COND) ? UH_WARP_FWD_MINW - 1 : UH_
     const int lane = threadIdx.x & 63, wave = wave_id();
     unsigned char* lds = lds_all + (STAGE_FWD ? wave * LDSW : 0);
     float cnt = 0.f;
-#ifdef UH_XCD_CHUNK_ROWS
-    const unsigned v = xcd_remap_chunked(blockIdx.x, nblk, (unsigned)(UH_XCD_CHUNK_ROWS * tiles_x));
-#else
     const unsigned v = xcd_remap(blockIdx.x, nblk);
-#endif
     const int b = v / tiles, tile = v - b * tiles;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int col = (tx * NWAVE + wave) * TW + (lane & (TW - 1));

@@ -619,10 +619,6 @@ def photometric_tail(pts1, h4p, U, I2, patch_indices, patch_size, fused_patch=Fa
 
 
 # ------------------------------------------------------------------------------------------------
-import os as _os
-_EXPERIMENT_MIOPEN_FUSED_RELU = _os.environ.get('UH_CONV_FUSED_RELU', '0') == '1'
-
-
 class _ConvBiasReLU(torch.autograd.Function):
     """relu(conv2d(x, w) + b) with the conv on stock MIOpen and the bias+ReLU epilogue (and its backward, including
     the bias gradient) as one HIP pass each (csrc/uh_epilogue.hip).  Activations are channels_last (NHWC storage)."""
@@ -630,19 +626,15 @@ class _ConvBiasReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, padding):
         lib = _lib.load()
-        if _EXPERIMENT_MIOPEN_FUSED_RELU:
-            # round-5 A/B: PyTorch-ROCm's aten::miopen_convolution_relu (MIOpen fusion plan conv + bias + ReLU
-            # where MIOpen has one for the problem) instead of conv + the HIP bias/ReLU pass; the backward is unchanged
-            y = torch.ops.aten.miopen_convolution_relu(x, weight, _f32(bias, 'bias'), [1, 1], [padding, padding], [1, 1], 1)
-            if not y.is_contiguous(memory_format=torch.channels_last):
-                y = y.contiguous(memory_format=torch.channels_last)
-        else:
-            y = torch.nn.functional.conv2d(x, weight, None, 1, padding)
-            if not y.is_contiguous(memory_format=torch.channels_last):
-                y = y.contiguous(memory_format=torch.channels_last)
-            N, Cc, Hh, Ww = y.shape
-            _lib.check(lib.uh_bias_relu_forward(_ptr(y), _ptr(_f32(bias, 'bias')), N * Hh * Ww, Cc, _stream()),
-                       'uh_bias_relu_forward')
+        # (PyTorch-ROCm's fused aten::miopen_convolution_relu was measured as a replacement for conv + this pass in round 5:
+        #  miopenStatusUnknownError on channels_last inputs at batch 64, and 0.8 - 2.3 x the time of this route on NCHW copies:
+        #  profiles/r05_conv_relu_probe.jsonl)
+        y = torch.nn.functional.conv2d(x, weight, None, 1, padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        N, Cc, Hh, Ww = y.shape
+        _lib.check(lib.uh_bias_relu_forward(_ptr(y), _ptr(_f32(bias, 'bias')), N * Hh * Ww, Cc, _stream()),
+                   'uh_bias_relu_forward')
         ctx.save_for_backward(x, weight, y)
         ctx.padding = padding
         return y
