@@ -68,6 +68,7 @@ def main():
         pr = _lib.profile_read(); _lib.profile_enable(False)
         ev_us = pr['warp_forward'][0] / max(pr['warp_forward'][1], 1) * 1e3
         t = tr.cpu().numpy().reshape(nw, 16).astype(np.int64)
+        widx = np.arange(nw)[(t[:, 8] > 0) & (t[:, 9] > 0)]     # wave record index = (virtual block id) * 4 + wave
         t = t[(t[:, 8] > 0) & (t[:, 9] > 0)]
         rt0, rt1 = t[:, 8], t[:, 9]                            # 100 MHz ticks
         origin = rt0.min()
@@ -86,13 +87,52 @@ def main():
         data_landed = s_us + (t[:, 3] - t[:, 0]) / mt_per_us    # per wave: when its data was there (DMA landed / loads returned)
         stores_issued = s_us + (t[:, 4] - t[:, 0]) / mt_per_us
         xcc = t[:, 10] & 0xF
-        per_xcd = {int(x): {'waves': int((xcc == x).sum()), 'first_start_us': round(float(s_us[xcc == x].min()), 2),
-                            'last_end_us': round(float(e_us[xcc == x].max()), 2)} for x in np.unique(xcc)}
         names = {0: 'A', 1: 'B', 2: 'C1', 3: 'C2'}
+        okx = lambda x: (xcc == x) & ok
+        per_xcd = {int(x): {'waves': int((xcc == x).sum()), 'first_start_us': round(float(s_us[xcc == x].min()), 2),
+                            'last_end_us': round(float(e_us[xcc == x].max()), 2),
+                            'end_us_all_but_64_waves': round(float(np.sort(e_us[xcc == x])[-65]), 2) if (xcc == x).sum() > 65 else None,
+                            # is a slow XCD slow because of its WORK (share of gather waves) or because of its CLOCK (shader ticks per us)?
+                            'gather_share': round(float(((t[:, 5] == 1) | (t[:, 5] == 3))[xcc == x].mean()), 3),
+                            'shader_ticks_per_us': round(float(np.median(life_mt[okx(x)] / (life_rt[okx(x)] / 100.0))), 0) if okx(x).any() else None,
+                            'mean_wave_life_us': round(float(life_rt[xcc == x].mean() / 100.0), 2),
+                            'sum_of_wave_lifetimes_ms': round(float(life_rt[xcc == x].sum() / 100.0 / 1e3), 2)} for x in np.unique(xcc)}
         paths = {names[k]: {'share': round(float((t[:, 5] == k).mean()), 4),
                             'mean_life_us': round(float(life_rt[t[:, 5] == k].mean() / 100.0), 2),
                             'mean_start_us': round(float(s_us[t[:, 5] == k].mean()), 2)} for k in names if (t[:, 5] == k).any()}
-        row = {'rep': rep, 'shape': a.shape, 'input': 'warm' if a.warm else 'cold (1 GiB evicting copy before the launch)',
+        # who makes the tail: path mix of the waves that END in the last 2 us / the last 1 us, and of the last generation (the
+        # waves that start after 90 % of all waves have started), with their lifetimes -- would dispatching gather tiles first help?
+        late2, late1 = e_us > span - 2.0, e_us > span - 1.0
+        lastgen = s_us >= np.percentile(s_us, 90)
+        mix = lambda m: {names[k]: round(float((t[m, 5] == k).mean()), 3) for k in names if m.any() and (t[m, 5] == k).any()}
+        life_by = lambda m: {names[k]: round(float(life_rt[m & (t[:, 5] == k)].mean() / 100.0), 2) for k in names if (m & (t[:, 5] == k)).any()}
+        tail_who = {'ending_in_last_2us': {'waves': int(late2.sum()), 'mix': mix(late2)},
+                    'ending_in_last_1us': {'waves': int(late1.sum()), 'mix': mix(late1)},
+                    'last_generation_(last_10pct_to_start)': {'mix': mix(lastgen), 'mean_life_us_by_path': life_by(lastgen),
+                                                              'p99_life_us': round(float(np.percentile(life_rt[lastgen], 99) / 100.0), 2),
+                                                              'mean_end_us_by_path': {names[k]: round(float(e_us[lastgen & (t[:, 5] == k)].mean()), 2)
+                                                                                      for k in names if (lastgen & (t[:, 5] == k)).any()}},
+                    'all_waves_mix': mix(np.ones(len(t), bool))}
+        # the stragglers themselves: the 24 waves that end last -- where they sit, when they started, which phase was long
+        tiles_x, tiles_y = (W + 63) // 64, (H + 15) // 16
+        order = np.argsort(-e_us)[:24]
+        ph = lambda i, a_, b_: round(float((t[i, b_] - t[i, a_]) / mt_per_us), 2)
+        stragglers = [{'end_us': round(float(e_us[i]), 2), 'start_us': round(float(s_us[i]), 2), 'life_us': round(float(life_rt[i] / 100.0), 2),
+                       'path': names.get(int(t[i, 5]), '?'), 'xcd': int(xcc[i]), 'image': int(widx[i] // 4 // (tiles_x * tiles_y)),
+                       'tile_y': int((widx[i] // 4 % (tiles_x * tiles_y)) // tiles_x), 'tile_x': int((widx[i] // 4 % (tiles_x * tiles_y)) % tiles_x),
+                       'wave': int(widx[i] % 4), 'cu_hwid': int(t[i, 11] & 0xFFFF),
+                       'coords_us': ph(i, 0, 1), 'issue_us': ph(i, 1, 2), 'wait_data_us': ph(i, 2, 3), 'consume_us': ph(i, 3, 4), 'store_drain_us': ph(i, 4, 7)}
+                      for i in order]
+        typical = {'coords_us': round(float(np.median((t[:, 1] - t[:, 0]) / mt_per_us)), 2), 'issue_us': round(float(np.median((t[:, 2] - t[:, 1]) / mt_per_us)), 2),
+                   'wait_data_us': round(float(np.median((t[:, 3] - t[:, 2]) / mt_per_us)), 2), 'consume_us': round(float(np.median((t[:, 4] - t[:, 3]) / mt_per_us)), 2),
+                   'store_drain_us': round(float(np.median((t[:, 7] - t[:, 4]) / mt_per_us)), 2),
+                   'p99_wait_data_us': round(float(np.percentile((t[:, 3] - t[:, 2]) / mt_per_us, 99)), 2),
+                   'p99_store_drain_us': round(float(np.percentile((t[:, 7] - t[:, 4]) / mt_per_us, 99)), 2),
+                   'p999_store_drain_us': round(float(np.percentile((t[:, 7] - t[:, 4]) / mt_per_us, 99.9)), 2),
+                   'p999_wait_data_us': round(float(np.percentile((t[:, 3] - t[:, 2]) / mt_per_us, 99.9)), 2)}
+        ends_sorted = np.sort(e_us)
+        row = {'rep': rep, 'shape': a.shape, 'tail_who': tail_who, 'stragglers': stragglers, 'median_and_p99_phases': typical,
+               'end_us_when_all_but_N_waves_are_done': {str(n): round(float(ends_sorted[-n - 1]), 2) for n in (1000, 256, 64, 16, 4, 0)}, 'input': 'warm' if a.warm else 'cold (1 GiB evicting copy before the launch)',
                'event_duration_us': round(ev_us, 2), 'wave_span_us': round(span, 2),
                'dispatch_overhead_us': round(ev_us - span, 2), 'waves': int(len(t)), 'blocks': nblk,
                'shader_clock_MHz_during_launch': round(mt_per_us, 0),
