@@ -4,8 +4,9 @@ Keeps the reference's CLI flags (:49-85), optimizer and learning-rate law (:161-
 exponential_decay(lr, step, int(decay_steps), 0.96, staircase) with
 decay_steps = ln(.96)*150000/ln(min_lr/lr)), the per-tower model construction (:229-257), gradient
 averaging (:277-278 -> dist.GradAverager over RCCL) and the test-mode statistics (:391-580), as an
-eager one-process-per-GPU program.  The TF queue-runner input pipeline (dataloader.py) is out of scope
-(SURVEY section 8): pairs come from synthetic.make_batch with the same sampling law, resident in HBM.
+eager one-process-per-GPU program.  Inputs: with --data_path, the reference's on-disk layout through dataloader.Dataloader
+(decode worker processes + uh_prepare_inputs: dataloader.py:76-235, joint augmentation in train mode, disjoint in test mode);
+without it, synthetic.make_batch draws pairs with the same sampling law directly in HBM.
 
     python -m unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic --mode train --batch_size 64 \
         --loss_type l1_loss --num_total_steps 200
