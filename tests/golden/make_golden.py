@@ -17,6 +17,11 @@ Two kinds of vectors:
     extracted from utils/utils.py:11-122 with `ast` (the module itself cannot be imported: it needs
     cv2, tensorflow and a TTY).
 
+  * ref_numpy_transformer_rgb.npz (round 5) -- the same reference functions applied CHANNEL BY CHANNEL to a 3-channel image (the
+    reference's own 3-channel branch, `np.expand_dims(wa, 2)` :88-91, raises under numpy >= 2; bilinear sampling acts on each
+    channel independently, so three gray calls ARE its 3-channel semantics).  Pins the oracle's C = 3 path -- the shape the
+    product runs -- to reference code instead of to the restatement alone.  `python make_golden.py rgb` writes only this file.
+
 (2) ORACLE-DERIVED (freeze the f64/f32 oracle so later edits cannot drift silently, and give the
     GPU tests fixed inputs+outputs that travel to the GPU box)
   * chain_small.npz -- full photometric chain fwd+bwd on a small seeded batch.
@@ -80,6 +85,28 @@ def reference_dlt_system(aux, pts1, h4p):
     return A.astype(f), b.astype(f)
 
 
+def main_rgb():
+    """ref_numpy_transformer_rgb.npz: the reference's _meshgrid / _interpolate, one call per channel of an RGB image, under
+    the reference's self-test homography (:157), a mild perspective and a strong one whose samples leave the frame."""
+    ref = import_reference_numpy_transformer()
+    rs = np.random.RandomState(4321)
+    H_, W_ = 40, 56
+    img = rs.uniform(0, 255, size=(H_, W_, 3))                    # RGB, f64
+    M = np.array([[W_ / 2.0, 0, W_ / 2.0], [0, H_ / 2.0, H_ / 2.0], [0, 0, 1.]]).astype(np.float32)
+    Hs = [np.array([[2., 0.3, 5], [0.3, 2., 10.], [0.0001, 0.0002, 1.]], np.float32),   # :157
+          np.array([[0.95, 0.08, -2.], [-0.06, 1.05, 3.], [3e-4, -2e-4, 1.]], np.float32),
+          np.array([[1.4, -0.3, -25.], [0.25, 0.7, 12.], [3e-3, 1e-3, 1.]], np.float32)]
+    thetas, outs = [], []
+    for Hm in Hs:
+        theta = np.dot(np.dot(np.linalg.inv(M), np.linalg.inv(Hm)), M)      # numpy_transformer() :136-141
+        T = np.dot(theta, ref._meshgrid(H_, W_))
+        xs, ys = T[0] / T[2], T[1] / T[2]
+        chans = [ref._interpolate(np.ascontiguousarray(img[:, :, c]), xs, ys, [H_, W_]).reshape(H_, W_) for c in range(3)]
+        thetas.append(theta); outs.append(np.stack(chans, 2))
+    np.savez_compressed(os.path.join(HERE, 'ref_numpy_transformer_rgb.npz'), img=img, thetas=np.stack(thetas), outs=np.stack(outs))
+    print('ref_numpy_transformer_rgb.npz written to', HERE)
+
+
 def main():
     from oracle import hotpath_numpy as O
     rs = np.random.RandomState(1234)
@@ -139,4 +166,8 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:] == ['rgb']:
+        main_rgb()
+    else:
+        main()
+        main_rgb()

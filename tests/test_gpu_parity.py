@@ -121,6 +121,21 @@ def test_warp_forward_reference_test_homography(ops, dev, golden):
         assert np.percentile(err, 99) < 5e-3
 
 
+def test_warp_forward_rgb_vs_reference_code_per_channel(ops, dev, golden):
+    """Round 5: the C = 3 kernel -- the instantiation the product runs -- against REFERENCE CODE: the reference's
+    _meshgrid / _interpolate applied channel by channel (tests/golden/make_golden.py rgb).  Bit-equal to the f32 oracle, and
+    within f32 rounding of the reference's f64 values (which carry no eps-guard and no x86 cast: in-frame behaviour)."""
+    g = golden('ref_numpy_transformer_rgb.npz')
+    img = g['img'].astype(np.float32)[None]
+    for i in range(g['thetas'].shape[0]):
+        th = g['thetas'][i].astype(np.float32)[None]
+        out, _ = ops.transformer(T(img, dev), T(th, dev), (40, 56))
+        ref32, _ = O.transformer(img, th, (40, 56), np.float32)
+        assert_same_bits(out.cpu().numpy(), ref32, 'rgb theta %d' % i)
+        err = np.abs(out.cpu().numpy()[0] - g['outs'][i])
+        assert np.percentile(err, 99) < 5e-3, (i, np.percentile(err, 99))
+
+
 @pytest.mark.parametrize('C', [1, 2, 3, 4])
 @pytest.mark.parametrize('shape', [(1, 37, 53, 37, 53), (3, 20, 30, 41, 70), (2, 64, 64, 16, 200)])
 def test_warp_forward_shapes_channels(ops, dev, C, shape):

@@ -23,6 +23,22 @@ def test_warp_matches_reference_numpy_transformer(golden):
         assert np.percentile(err, 99) < 5e-3, np.percentile(err, 99)
 
 
+def test_rgb_warp_matches_reference_numpy_transformer_per_channel(golden):
+    """ref_numpy_transformer_rgb.npz (round 5) = the reference's _meshgrid + _interpolate called once per channel of an RGB image
+    (its own 3-channel branch raises under numpy >= 2; bilinear sampling is per channel, so this IS its C = 3 semantics): the
+    oracle's C = 3 path -- the shape the product runs -- agrees with reference code, not only with the restatement."""
+    g = golden('ref_numpy_transformer_rgb.npz')
+    img = g['img']
+    assert img.shape == (40, 56, 3)
+    for i in range(g['thetas'].shape[0]):
+        out, _ = O.transformer(img[None], g['thetas'][i][None], (40, 56), np.float64)
+        np.testing.assert_allclose(out[0], g['outs'][i], rtol=0, atol=1e-10)
+        out32, _ = O.transformer(img[None].astype(np.float32), g['thetas'][i][None].astype(np.float32), (40, 56), np.float32)
+        err = np.abs(out32[0] - g['outs'][i])
+        assert np.percentile(err, 99) < 5e-3, (i, np.percentile(err, 99))
+    assert (g['outs'][2] == 0).mean() > 0.05            # the strong homography does leave the frame (out-of-range taps give 0 there)
+
+
 def test_dlt_system_matches_reference_aux_matrices(golden):
     """ref_dlt_system.npz = A, b built by the reference's formula with its own Aux_M* constants."""
     d = golden('ref_dlt_system.npz')
