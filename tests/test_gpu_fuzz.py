@@ -153,3 +153,67 @@ def test_fuzz_dlt_forward_and_backward(ops, dev):
         lim = bound * np.maximum(1.0, cond / 1e7)
         worst = int(np.argmax(err / lim))
         assert (err <= lim).all(), (f64, float(err[worst]), float(cond[worst]), float(np.median(err)))
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_fuzz_prepare_inputs(dev, uh_lib_path, seed):
+    """uh_prepare_inputs on random frame sizes (H*W % 4 == 0 -> the 4-pixels-per-lane path, otherwise the scalar one), patch sizes
+    and positions incl. patches touching the frame border, with joint / disjoint / identity augmentation rows mixed in one batch."""
+    from unsuperviseddeephomographyral2018_amd import dataloader as dl
+    rs = np.random.RandomState(5000 + seed)
+    for case in range(4):
+        B = int(rs.randint(1, 6)); H, W = int(rs.randint(8, 70)), int(rs.randint(8, 90))
+        P = int(rs.randint(2, min(H, W) + 1))
+        I = rs.randint(0, 256, (B, H, W, 3)).astype(np.uint8); Ip = rs.randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+        x0 = rs.randint(0, W - P + 1, B); y0 = rs.randint(0, H - P + 1, B)
+        pts1 = np.stack([x0, y0, x0 + P, y0, x0 + P, y0 + P, x0, y0 + P], 1).astype(np.float32)
+        aug = None
+        if case % 2 == 1:
+            aug = dl.sample_augmentation(B, 'train' if case == 1 else 'test', 0.7, torch.Generator().manual_seed(seed * 10 + case))
+        got = dl.prepare_inputs(torch.from_numpy(I).to(dev), torch.from_numpy(Ip).to(dev), torch.from_numpy(pts1), P, aug)
+        ref = O.prepare_inputs(I, Ip, pts1, P, None if aug is None else aug.numpy())
+        tol = 1e-6 if aug is None else 2e-4                    # powf: a few ulp of values up to 510, after standardisation
+        for k in ('I_aug', 'I_prime_aug', 'I1', 'I2', 'I1_aug', 'I2_aug'):
+            assert np.abs(got[k].cpu().numpy() - ref[k]).max() <= tol, (seed, case, k, B, H, W, P)
+        assert np.array_equal(got['patch_indices'].cpu().numpy(), ref['patch_indices']), (seed, case)
+
+
+@pytest.mark.parametrize('seed', range(3))
+def test_fuzz_patch_losses_and_fused_patch_path(ops, dev, seed):
+    """Six loss values for random B and P (3 .. 70: not multiples of the 16 x 16 SSIM tile or the 1 024-pixel loss chunk) against
+    the f64 restatement; and the fused patch kernel against the un-fused chain on random rectangles: pred_I2 bit-equal, the l1
+    value and d theta within the documented bounds."""
+    rs = np.random.RandomState(6000 + seed)
+    for case in range(4):
+        B = int(rs.randint(1, 7)); P = int(rs.randint(3, 71))
+        x = (rs.randn(B, P, P, 1) * 1.5).astype(np.float32)
+        y = (x + rs.randn(B, P, P, 1) * rs.choice([0.05, 0.8, 2.0], size=(B, 1, 1, 1))).astype(np.float32)
+        h4p = rs.randn(B, 8).astype(np.float32) * 20; gt = rs.randint(-45, 46, (B, 8)).astype(np.float32)
+        got = ops.patch_losses(T(x, dev), T(y, dev), T(h4p, dev), T(gt, dev)).cpu().numpy()
+        ref = O.patch_losses(x, y, h4p, gt)
+        for i, k in enumerate(('rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss', 'h_loss')):
+            assert abs(got[i] - ref[k]) <= 1e-5 * max(1.0, abs(ref[k])), (seed, case, B, P, k, got[i], ref[k])
+    for case in range(4):
+        B = int(rs.randint(1, 5)); C = int(rs.randint(1, 5))
+        H, W = int(rs.randint(24, 100)), int(rs.randint(24, 130))
+        P = int(rs.randint(4, min(H, W) - 1))
+        lo = rs.rand(B, H // 4 + 2, W // 4 + 2, C).astype(np.float32)
+        U = torch.nn.functional.interpolate(torch.from_numpy(lo).permute(0, 3, 1, 2), size=(H, W), mode='bilinear',
+                                            align_corners=True).permute(0, 2, 3, 1).contiguous().numpy()
+        theta = _random_theta(rs, B, 'mild')
+        x0 = rs.randint(0, W - P + 1, B); y0 = rs.randint(0, H - P + 1, B)
+        u = np.arange(P)
+        idx = ((u[None, :, None] + y0[:, None, None]) * W + (u[None, None, :] + x0[:, None, None])).reshape(B, P * P).astype(np.int32)
+        I2 = rs.rand(B, P, P, 1).astype(np.float32)
+        Ut, it, I2t = T(U, dev), T(idx, dev), T(I2, dev)
+        th1 = T(theta, dev).requires_grad_(True)
+        loss1, pred1 = ops.warp_patch_l1(Ut, th1, I2t, it, P)
+        loss1.backward()
+        th2 = T(theta, dev).requires_grad_(True)
+        _, pred2 = ops.warp_gather(Ut, th2, it, P)
+        loss2 = ops.patch_losses(pred2, I2t, train='l1_loss')[2]
+        loss2.backward()
+        what = 'seed %d case %d: B%d %dx%dx%d P%d' % (seed, case, B, H, W, C, P)
+        assert torch.equal(pred1, pred2), what
+        assert abs(float(loss1.detach()) - float(loss2.detach())) <= 1e-6 * max(1.0, abs(float(loss2.detach()))), what
+        assert relerr(th1.grad.cpu().numpy(), th2.grad.cpu().numpy()) <= 2e-4, what
