@@ -90,6 +90,8 @@ for ST in "$@"; do
             grep -E "^\||dataset|trained|RESULT|Average|ercentile|per-pair" gpurun_out/${TAG}_train_from_disk_reference_schedule.txt | cut -c1-500; grep "Train: step" gpurun_out/${TAG}_train_from_disk_reference_schedule.txt | tail -3 | cut -c1-300; tail -3 gpurun_out/${TAG}_train_from_disk_reference_schedule.err ;;
     conv_relu_probe) ( cd /tmp && rm -rf /tmp/pcr_$TAG && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pcr_$TAG -o cr --output-format csv -- python /root/repo/tools/conv_relu_probe.py > /root/repo/gpurun_out/${TAG}_conv_relu_probe.jsonl 2> /root/repo/gpurun_out/${TAG}_conv_relu_probe.err )
             cp $(find /tmp/pcr_$TAG -name "*kernel_stats*" | head -1) gpurun_out/${TAG}_conv_relu_probe_kernel_stats.csv 2>/dev/null; cut -c1-400 gpurun_out/${TAG}_conv_relu_probe.jsonl ;;
+    pmc_cold) ( cd /tmp && rm -rf /tmp/pmccw && mkdir -p /tmp/pmccw && for T in 1 0; do i=0; for CN in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE"; do i=$((i+1)); timeout 200 rocprofv3 --pmc $CN --kernel-trace -d /tmp/pmccw/cold${T}_group$i -o p --output-format csv -- python /root/repo/tools/pmc_cold_warm.py run --cold $T > /tmp/pmccw_log_${T}_$i.txt 2>&1 || { echo "pass cold=$T group $i failed"; tail -3 /tmp/pmccw_log_${T}_$i.txt; }; done; done )
+            python tools/pmc_cold_warm.py parse /tmp/pmccw > gpurun_out/${TAG}_pmc_cold_warm.jsonl; cat gpurun_out/${TAG}_pmc_cold_warm.jsonl ;;
     cpu_threads) timeout 900 python bench.py --cpu_threads_sweep 8,32,64,128,256 > gpurun_out/${TAG}_cpu_threads.txt 2> gpurun_out/${TAG}_cpu_threads.err; cut -c1-200 gpurun_out/${TAG}_cpu_threads.txt ;;
     dp)     timeout 900 python -m pytest tests/test_gpu_dp_product.py -m gpu -q -s --tb=short > gpurun_out/${TAG}_pytest_dp_product.log 2>&1; grep -E "world 2|passed|failed|Error|error" gpurun_out/${TAG}_pytest_dp_product.log | tail -12 ;;
     bench8) # `python bench.py --gpus 8` on ONE GPU: 8 gloo ranks (functional run of the N = 8 plumbing), wall time with the conv
