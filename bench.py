@@ -22,6 +22,9 @@ Rank 0 prints ONE JSON line; extra objects:
   cpu_baseline -- the reference-equivalent op graph on torch-CPU (oracle/hotpath_torch.py) timed on this
                   box's host cores on a bounded sample of the same workload: the GPU leg's batch and corner offsets,
                   copied to the host (rank 0, N=1 only).
+  exchange     -- N > 1 only (dist.exchange_report): each bucket's stand-alone all-reduce time with busbw against (n - 1) x 153 GB/s
+                  of xGMI, ms_per_step_no_exchange (10 more steps with the averager disabled on every rank) and
+                  exchange_cost_ms_per_step = ms_per_step - that: what the gradient exchange really costs, contention included.
   quality      -- the metric's second half, "mean corner error": a from-scratch unsupervised l1_loss training with the
                   reference's hyper-parameters for a fixed step budget OUTSIDE the timed region, then the reference's
                   test statistics (homography_CNN_synthetic.py:391-401,573-579) on held-out pairs (rank 0, N=1 only).
