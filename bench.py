@@ -466,18 +466,10 @@ def config4_point(device, args):
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): become
-    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py
-    <same arguments>` -- one rank per GPU; the ranks pick RCCL when every rank has a device of its own and gloo otherwise
-    (dist.init_from_env), so the same command is a functional run on a 1-GPU box."""
-    import socket
-    with socket.socket() as so:
-        so.bind(('127.0.0.1', 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stdout.flush(); sys.stderr.flush()
-    os.execv(sys.executable, cmd)
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: dist.self_launch re-executes this file under
+    torch.distributed.run with the same arguments (the driver contract's command line)."""
+    from unsuperviseddeephomographyral2018_amd import dist as uh_dist
+    uh_dist.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
 
 def main():

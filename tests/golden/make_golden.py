@@ -22,6 +22,13 @@ Two kinds of vectors:
     channel independently, so three gray calls ARE its 3-channel semantics).  Pins the oracle's C = 3 path -- the shape the
     product runs -- to reference code instead of to the restatement alone.  `python make_golden.py rgb` writes only this file.
 
+  * ref_find_percentile.npz (round 6) -- outputs of the reference's utils.find_percentile (utils/utils.py:655-672), extracted with
+    `ast` like Aux_M* and executed as-is, on the reference's own test vector (test_find_percentile, :675) and on seeded vectors
+    of several lengths.  `python make_golden.py percentile` writes only this file.
+  * ref_cli_flags.json (round 6) -- every parser.add_argument of homography_CNN_synthetic.py:49-85 (flag, type name, nargs,
+    choices, default where it is a literal) read with `ast`, plus the README's homography_CNN_synthetic.py command lines with
+    their line numbers.  Data for tests/test_cli.py.  `python make_golden.py cli` writes only this file.
+
 (2) ORACLE-DERIVED (freeze the f64/f32 oracle so later edits cannot drift silently, and give the
     GPU tests fixed inputs+outputs that travel to the GPU box)
   * chain_small.npz -- full photometric chain fwd+bwd on a small seeded batch.
@@ -83,6 +90,60 @@ def reference_dlt_system(aux, pts1, h4p):
     A = np.transpose(np.stack(cols, axis=1), (0, 2, 1))
     b = (M['Aux_Mb'] @ p2_t).reshape(-1, 8)
     return A.astype(f), b.astype(f)
+
+
+def extract_find_percentile():
+    """utils.find_percentile (utils/utils.py:655-672) as a callable: the FunctionDef node is compiled as-is (the module cannot
+    be imported: cv2, tensorflow, a TTY); its print() calls are silenced."""
+    src = open(os.path.join(REF, 'utils', 'utils.py')).read()
+    ns = {'np': np, 'print': lambda *a, **k: None}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name == 'find_percentile':
+            exec(compile(ast.Module([node], []), 'utils.py', 'exec'), ns)
+    return ns['find_percentile']
+
+
+def main_percentile():
+    fp = extract_find_percentile()
+    rs = np.random.RandomState(655)
+    out = {}
+    x_ref = np.array([10, 1.10, 2, 3, 4, 5, 6, 6, 7, 8, 9], np.float64)          # test_find_percentile (:675)
+    out['x_ref'] = x_ref; out['y_ref'] = np.asarray(fp(list(x_ref)), np.float64)
+    for n in (3, 4, 10, 24, 100, 1001):                                          # 24 = 3 epochs x 8 test batches
+        x = np.abs(rs.randn(n) * 6.0 + 5.0)
+        out['x_%d' % n] = x; out['y_%d' % n] = np.asarray(fp(x), np.float64)
+    x32 = (rs.rand(37) * 40).astype(np.float32)                                  # the trainer hands it float32 per-pair arrays too
+    out['x_f32'] = x32; out['y_f32'] = np.asarray(fp(x32), np.float64)
+    np.savez_compressed(os.path.join(HERE, 'ref_find_percentile.npz'), **out)
+    print('ref_find_percentile.npz written to', HERE)
+
+
+def main_cli():
+    import json
+    src = open(os.path.join(REF, 'homography_CNN_synthetic.py')).read()
+    flags = []
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == 'add_argument' \
+                and isinstance(node.func.value, ast.Name) and node.func.value.id == 'parser':
+            kw = {k.arg: k.value for k in node.keywords}
+            ent = {'flag': node.args[0].value, 'line': node.lineno,
+                   'type': kw['type'].id if 'type' in kw else None,
+                   'nargs': kw['nargs'].value if 'nargs' in kw else None,
+                   'choices': ast.literal_eval(kw['choices']) if 'choices' in kw else None}
+            try:
+                ent['default'] = ast.literal_eval(kw['default']); ent['default_is_literal'] = True
+            except (ValueError, KeyError):
+                ent['default'] = kw['default'].id if isinstance(kw.get('default'), ast.Name) else None
+                ent['default_is_literal'] = False
+            flags.append(ent)
+    flags.sort(key=lambda e: e['line'])
+    cmds = []
+    for i, line in enumerate(open('/root/reference/README.md').read().splitlines(), 1):
+        if line.strip().startswith('python homography_CNN_synthetic.py'):
+            cmds.append({'line': i, 'argv': line.strip().split()[2:]})
+    with open(os.path.join(HERE, 'ref_cli_flags.json'), 'w') as f:
+        json.dump({'source': 'code/homography_CNN_synthetic.py:49-85 + README.md', 'flags': flags, 'readme_commands': cmds}, f, indent=1)
+    print('ref_cli_flags.json: %d flags, %d README commands' % (len(flags), len(cmds)))
 
 
 def main_rgb():
@@ -168,6 +229,12 @@ def main():
 if __name__ == '__main__':
     if sys.argv[1:] == ['rgb']:
         main_rgb()
+    elif sys.argv[1:] == ['percentile']:
+        main_percentile()
+    elif sys.argv[1:] == ['cli']:
+        main_cli()
     else:
         main()
         main_rgb()
+        main_percentile()
+        main_cli()

@@ -63,6 +63,52 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def self_launch(nproc, target, argv, module=False):
+    """A program asked for `nproc` > 1 GPUs (bench.py --gpus N; the trainer's --num_gpus N, the reference's tower count,
+    homography_CNN_synthetic.py:56,199-207) with no launcher around it (no WORLD_SIZE in the environment): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> <target>
+    <same arguments>` -- one rank per GPU; the ranks pick RCCL when every rank has a device of its own and gloo otherwise
+    (init_from_env), so the same command is a functional run on a 1-GPU box.  `target` is a script path, or a module name
+    with module=True (torchrun's -m).  Replaces the process: does not return."""
+    import socket
+    import sys
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(nproc)),
+           '--master-addr', '127.0.0.1', '--master-port', str(port)]
+    cmd += (['-m', target] if module else [os.path.abspath(target)]) + list(argv)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def resolve_num_gpus(num_gpus, batch_size=None):
+    """What the reference's --num_gpus (number of towers the batch is tf.split over, homography_CNN_synthetic.py:56,199-207)
+    means with one process per GPU.  -> ('run', world) to go on in this process, or ('launch', N) when the caller must
+    self_launch N ranks.  Never silently ignored:
+      not given (None)            the launcher decides: WORLD_SIZE, or 1 without a launcher
+      N, no launcher, N == 1      one rank, this process
+      N, no launcher, N > 1       ('launch', N)
+      N, under a launcher         must equal WORLD_SIZE, otherwise ValueError
+    and the batch must split evenly over the towers, as tf.split demands."""
+    env_world = os.environ.get('WORLD_SIZE')
+    if num_gpus is not None and int(num_gpus) < 1:
+        raise ValueError('--num_gpus must be >= 1, got %s' % num_gpus)
+    if env_world is not None:
+        world = int(env_world)
+        if num_gpus is not None and int(num_gpus) != world:
+            raise ValueError('--num_gpus %d contradicts the launcher: WORLD_SIZE=%d (one process per GPU; start %d ranks, or '
+                             'drop --num_gpus)' % (int(num_gpus), world, int(num_gpus)))
+    else:
+        world = 1 if num_gpus is None else int(num_gpus)
+    if batch_size is not None and int(batch_size) % world:
+        raise ValueError('--batch_size %d does not split over %d towers (tf.split would fail the same way)' % (int(batch_size), world))
+    if env_world is None and world > 1:
+        return 'launch', world
+    return 'run', world
+
+
 def skip_naive_conv_in_find():
     """MIOpen's find mode (torch.backends.cudnn.benchmark) also BENCHMARKS its reference solvers -- naive_conv_*: one thread per
     output, 0.3 s per launch for this network's weight gradients; 48 + 48 + 40 launches = 16.7 of the ~40 s the first step of a

@@ -47,7 +47,10 @@ def build_parser():
     p.add_argument('--augment_list', nargs='+', default=AUGMENT_LIST, help='List of augmentations')
     p.add_argument('--do_augment', type=float, default=0.5)
     p.add_argument('--num_gpus', type=int, default=None,
-                   help='Number of splits.  Here = WORLD_SIZE (one process per GPU); kept for CLI compatibility')
+                   help='Number of splits (towers) of the batch.  One process per GPU here: without a launcher, N > 1 re-executes '
+                        'this program under torch.distributed.run with N ranks (RCCL when N GPUs are visible, gloo sharing the '
+                        'visible ones otherwise); under a launcher it must equal WORLD_SIZE (error otherwise).  Not given = the '
+                        'launcher decides (WORLD_SIZE, else 1) -- the reference\'s default of 2 would fail on a 1-GPU box')
     p.add_argument('--log_dir', type=str, default='../logs/')
     p.add_argument('--results_dir', type=str, default='../results/synthetic/report/')
     p.add_argument('--model_dir', type=str, default='../models/synthetic_models')
@@ -60,6 +63,13 @@ def build_parser():
     p.add_argument('--test_gt_file', type=str, default='')
     p.add_argument('--filenames_file', type=str, default='', help='File that contains all names of files, for training')
     p.add_argument('--test_filenames_file', type=str, default='')
+    # accepted for command-line compatibility (:64-65, :73-74).  --I_dir / --I_prime_dir are parsed and never read by the
+    # reference either (its Dataloader joins data_path + 'I/' / 'I_prime/', dataloader.py:143-144); --visual / --save_visual
+    # drive its matplotlib / cv2 side (:117, :334, :362-387, :539-567), which is outside the hot path: main() says so once
+    p.add_argument('--I_dir', type=str, default='', help='The training image path (unused, as in the reference: data_path + I/)')
+    p.add_argument('--I_prime_dir', type=str, default='', help='The training image path (unused: data_path + I_prime/)')
+    p.add_argument('--visual', type=str2bool, default='false', help='Visualize obtained images to debug (accepted; no plotting here)')
+    p.add_argument('--save_visual', type=str2bool, default='True', help='Save visual images for report (accepted; nothing is drawn here)')
     p.add_argument('--img_w', type=int, default=WIDTH)
     p.add_argument('--img_h', type=int, default=HEIGHT)
     p.add_argument('--patch_size', type=int, default=PATCH_SIZE)
@@ -491,8 +501,8 @@ class TestHomography(object):
                     device=self.device, kind=getattr(a, 'texture', 'smooth'))
                 m = HomographyModel(self.params, *synthetic.model_args(batch), reuse_variables=True, net=self.net,
                                     solve_f64=a.solve_f64)
-                per_step.append(float(m.bounded_h_loss))                   # h_losses_array.append(h_loss_value) (:537)
-                total_bounded += per_step[-1]
+                per_step.append(np.float32(float(m.bounded_h_loss)))       # h_losses_array.append(h_loss_value) (:537): float32, as fetched
+                total_bounded += float(per_step[-1])
                 total_fail += float(m.num_fail)
                 per_pair.append(torch.sqrt(torch.mean((m.pred_h4p - m.gt) ** 2, dim=1)).cpu())
         self.net.train(was_training)
@@ -504,11 +514,11 @@ class TestHomography(object):
             'fail_percent': 100.0 * total_fail / (num_steps * a.batch_size),
             # the REFERENCE's printout (:577-579 -> utils.find_percentile, utils.py:655-672): [mean, std] of the sorted per-STEP
             # bounded h_loss values (one per test batch) in the intervals 0-30 %, 30-60 %, 60-100 %
-            'reference_percentile_intervals': find_percentile(per_step),
+            'reference_percentile_intervals': find_percentile(per_step).tolist(),
             # ... and two statistics the reference does not print (per PAIR, unbounded corner RMSE): point percentiles, and the
             # same three intervals -- the form the paper's bar charts use
             'percentiles': {q: float(np.percentile(per_pair, q)) for q in (20, 30, 50, 60, 80, 100)},
-            'per_pair_intervals': find_percentile(per_pair),
+            'per_pair_intervals': find_percentile(per_pair).tolist(),
             'num_pairs': int(per_pair.size),
         }
         print('====> Result for RHO:', a.rho, ' loss ', a.loss_type, ' noise ', getattr(a, 'do_augment', None) if disk is not None else 0.0)
@@ -522,23 +532,67 @@ class TestHomography(object):
 
 
 def find_percentile(x, tops_list=(0.3, 0.6, 1)):
-    """utils.find_percentile (utils/utils.py:655-672): sort x; [mean, std] of the intervals [0, 30 %), [30 %, 60 %), [60 %, 100 %)."""
-    xs = np.sort(np.asarray(x, dtype=np.float64))
+    """utils.find_percentile (utils/utils.py:655-672): sort x; [mean, std] of the intervals [0, 30 %), [30 %, 60 %), [60 %, 100 %),
+    in x's OWN dtype (the reference hands it the float32 values sess.run returned, so np.mean / np.std accumulate in float32);
+    an empty interval gives [nan, nan] as np.mean / np.std of an empty slice do.  Pinned to the reference's function by
+    tests/golden/ref_find_percentile.npz (tests/test_cli.py)."""
+    import warnings
+    xs = np.sort(x)
     out, start = [], 0
-    for t in tops_list:
-        stop = int(t * len(xs))
-        iv = xs[start:stop]
-        out.append([float(np.mean(iv)) if iv.size else float('nan'), float(np.std(iv)) if iv.size else float('nan')])
-        start = stop
-    return out
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)              # "Mean of empty slice": the reference prints it and goes on
+        for t in tops_list:
+            stop = int(t * len(xs))
+            iv = xs[start:stop]
+            out.append([np.mean(iv), np.std(iv)])
+            start = stop
+    return np.array(out)
+
+
+MODULE = 'unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic'
+
+
+def unsupported_flag_notes(args, argv):
+    """One line per reference flag that is accepted but has no effect here, only for flags the command line really set."""
+    given = {a.split('=')[0] for a in argv if a.startswith('--')}
+    notes = []
+    if args.visual:
+        notes.append('--visual True: the reference plots with matplotlib every step (:362-387, :559-567); there is no plotting side '
+                     'here -- training / testing runs without it')
+    if '--save_visual' in given and args.save_visual and args.mode == 'test':
+        notes.append('--save_visual True: the reference writes correspondence JPEGs into --results_dir with cv2 (:539-552); not drawn here')
+    for f in ('--I_dir', '--I_prime_dir'):
+        if f in given:
+            notes.append('%s: parsed and never read, exactly as in the reference (frames are data_path + I/ and I_prime/)' % f)
+    return notes
 
 
 def main(argv=None):
+    import sys
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
+    for note in unsupported_flag_notes(args, argv):
+        if int(os.environ.get('RANK', '0')) == 0:
+            print('note: ' + note, file=sys.stderr, flush=True)
+    try:
+        what, world = uh_dist.resolve_num_gpus(args.num_gpus, args.batch_size if args.mode == 'train' else None)
+    except ValueError as e:
+        raise SystemExit('homography_CNN_synthetic: %s' % e)
     if args.mode == 'train':
+        if what == 'launch':
+            if torch.cuda.is_available() and torch.cuda.device_count() < world:
+                print('note: --num_gpus %d with %d visible GPU(s): the ranks share the visible device(s) over gloo (a functional '
+                      'run, not a scaling run)' % (world, torch.cuda.device_count()), file=sys.stderr, flush=True)
+            uh_dist.self_launch(world, MODULE, argv, module=True)          # does not return
         train(args)
     else:
-        TestHomography(args).run()
+        if world > 1 and int(os.environ.get('RANK', '0')) == 0:
+            # the reference builds num_gpus towers in test mode too (:417-446) and averages their statistics: the figures do
+            # not depend on the split, so the test loop runs on one device
+            print('note: test mode evaluates on one GPU; --num_gpus / WORLD_SIZE %d does not change the statistics' % world,
+                  file=sys.stderr, flush=True)
+        if int(os.environ.get('RANK', '0')) == 0:
+            TestHomography(args).run()
 
 
 if __name__ == '__main__':
