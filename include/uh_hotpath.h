@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define UH_ABI_VERSION 7
+#define UH_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define UH_API __attribute__((visibility("default")))
@@ -259,6 +259,23 @@ UH_API int    uh_bias_relu_pool_forward(float* y, const float* bias, float* pool
 UH_API size_t uh_bias_relu_pool_backward_workspace_bytes(int N, int H, int W, int C);
 UH_API int    uh_bias_relu_pool_backward(const float* y, const float* gpooled, float* g, float* dbias, void* workspace,
                                   size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream);
+
+/* bit-mask variants: the forward keeps ONE BIT per element for the backward instead of the activation itself (ReLU: y > 0;
+ * pool: which window element receives the gradient, none when the window maximum is not positive), so the backward reads
+ * gy + bits instead of gy + y, and the pooled forward does not write relu(y + b) back at full resolution (nothing downstream
+ * reads it: the next conv consumes `pooled`).  `mask` is opaque: uh_relu_mask_bytes / uh_pool_mask_bytes bytes, produced by
+ * the forward and consumed by the backward of the SAME shape.  uh_bias_relu_pool_forward_bits accepts mask == NULL
+ * (forward only) and leaves y untouched.                                                                              */
+UH_API size_t uh_relu_mask_bytes(size_t npix, int C);
+UH_API int    uh_bias_relu_forward_bits(float* y, const float* bias, void* mask, size_t npix, int C, uh_stream_t stream);
+UH_API size_t uh_bias_relu_backward_bits_workspace_bytes(size_t npix, int C);
+UH_API int    uh_bias_relu_backward_bits(const void* mask, const float* gy, float* g, float* dbias, void* workspace,
+                                  size_t workspace_bytes, size_t npix, int C, uh_stream_t stream);
+UH_API size_t uh_pool_mask_bytes(int N, int H, int W, int C);
+UH_API int    uh_bias_relu_pool_forward_bits(const float* y, const float* bias, float* pooled, void* mask, int N, int H,
+                                      int W, int C, uh_stream_t stream);
+UH_API int    uh_bias_relu_pool_backward_bits(const void* mask, const float* gpooled, float* g, float* dbias, void* workspace,
+                                       size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream);
 
 /* ---- in-library kernel timing (used by bench.py for the roofline figure) -----------------------------
  * When enabled, every launch above is bracketed by hipEventRecord on ITS stream; uh_profile_read()

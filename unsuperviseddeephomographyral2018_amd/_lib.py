@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UH_LIB_PATH lets a developer A/B a differently-built copy of the SAME library (tools/); it is not a fallback.
 LIB_PATH = os.environ.get('UH_LIB_PATH') or os.path.join(HERE, 'lib', 'libuh_hotpath.so')
 
-UH_ABI_VERSION = 7
+UH_ABI_VERSION = 8
 UH_DLT_SOLVE_F32 = 0
 UH_DLT_SOLVE_F64 = 1
 UH_DLT_ZERO_NONFINITE_GRAD = 8
@@ -59,6 +59,13 @@ SIGNATURES = {
     'uh_bias_relu_pool_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'uh_bias_relu_pool_backward_workspace_bytes': (_z, [_i, _i, _i, _i]),
     'uh_bias_relu_pool_backward': (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
+    'uh_relu_mask_bytes': (_z, [_z, _i]),
+    'uh_bias_relu_forward_bits': (_i, [_p, _p, _p, _z, _i, _p]),
+    'uh_bias_relu_backward_bits_workspace_bytes': (_z, [_z, _i]),
+    'uh_bias_relu_backward_bits': (_i, [_p, _p, _p, _p, _p, _z, _z, _i, _p]),
+    'uh_pool_mask_bytes': (_z, [_i, _i, _i, _i]),
+    'uh_bias_relu_pool_forward_bits': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'uh_bias_relu_pool_backward_bits': (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     'uh_profile_enable': (_i, [_i]),
     'uh_profile_read': (_i, [_p, _p]),
     'uh_kernel_name': (C.c_char_p, [_i]),

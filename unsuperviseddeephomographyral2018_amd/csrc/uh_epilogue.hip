@@ -154,6 +154,141 @@ __global__ __launch_bounds__(256) void bias_relu_pool_backward_kernel(const floa
     }
 }
 
+// ---- the same two epilogues with the backward's knowledge kept as BITS instead of as the activation itself --------------
+// The backward of bias+ReLU needs one bit per element (y > 0); the backward of bias+ReLU+pool needs, per pooled element, which
+// of its four window elements received the gradient (none when the maximum is not positive).  Reading y back for that costs
+// 4 B/element in the backward, and the pooled variant must also WRITE relu(y + b) back at full resolution in the forward
+// although nothing downstream reads it (the next conv consumes `pooled`).  With the bits kept instead (1 bit per element):
+//   bias+ReLU       forward 8 -> 8.03 B/elem, backward 12 -> 8.03 B/elem
+//   bias+ReLU+pool  forward 9 -> 5.03 B/elem (of y), backward 9 -> 5.03 B/elem
+// Layout (opaque to the caller; produced by the forward, consumed by the backward):
+//   bias+ReLU       the float4 stream is cut into chunks of 128; lane l of the wave that owns chunk c holds float4 128c + l and
+//                   128c + 64 + l and stores ONE byte mask[64c + l] = bits(first) | bits(second) << 4 (64 B per wave, coalesced)
+//   pool            one uint16 per (pooled pixel, channel quad): bit 4k + j = "window element k of component j gets the gradient"
+//                   (k = 0..3: (2i,2j) (2i,2j+1) (2i+1,2j) (2i+1,2j+1); first maximum wins a tie, as max_pool2d; live = max > 0)
+__device__ __forceinline__ unsigned pos4(float4 v) {
+    return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+}
+__device__ __forceinline__ float4 keep4(float4 d, unsigned bits) {
+    return make_float4((bits & 1u) ? d.x : 0.f, (bits & 2u) ? d.y : 0.f, (bits & 4u) ? d.z : 0.f, (bits & 8u) ? d.w : 0.f);
+}
+
+__global__ __launch_bounds__(256) void bias_relu_forward_bits_kernel(float4* __restrict__ y, const float* __restrict__ bias,
+                                                                     unsigned char* __restrict__ mask, size_t n4, int q /* = C/4 */) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (size_t)gridDim.x * 4;
+    // q divides 256 and nwaves is a multiple of 4: the channel quads of a lane's two float4s never change along the loop
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + (int)((wave * 128 + lane) & (size_t)(q - 1)) * 4);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + (int)((wave * 128 + 64 + lane) & (size_t)(q - 1)) * 4);
+    const size_t nchunk = (n4 + 127) / 128;
+    for (size_t c = wave; c < nchunk; c += nwaves) {
+        const size_t i0 = c * 128 + lane, i1 = i0 + 64;
+        const bool ok0 = i0 < n4, ok1 = i1 < n4;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (ok0) v0 = y[i0];
+        if (ok1) v1 = y[i1];
+        v0 = relu_bias4(v0, b0); v1 = relu_bias4(v1, b1);
+        if (ok0) { y[i0] = v0; mask[c * 64 + lane] = (unsigned char)(pos4(v0) | (ok1 ? pos4(v1) << 4 : 0u)); }
+        if (ok1) y[i1] = v1;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_relu_backward_bits_kernel(const unsigned char* __restrict__ mask,
+                                                                      const float4* __restrict__ gy, float4* __restrict__ g,
+                                                                      float* __restrict__ partial, size_t n4, int q) {
+    __shared__ float4 sm[512];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (size_t)gridDim.x * 4;
+    const size_t nchunk = (n4 + 127) / 128;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    for (size_t c = wave; c < nchunk; c += nwaves) {
+        const size_t i0 = c * 128 + lane, i1 = i0 + 64;
+        const bool ok0 = i0 < n4, ok1 = i1 < n4;
+        unsigned bits = 0;
+        float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+        if (ok0) { bits = mask[c * 64 + lane]; d0 = gy[i0]; }
+        if (ok1) d1 = gy[i1];
+        d0 = keep4(d0, bits); d1 = keep4(d1, bits >> 4);
+        if (ok0) g[i0] = d0;
+        if (ok1) g[i1] = d1;
+        acc0.x += d0.x; acc0.y += d0.y; acc0.z += d0.z; acc0.w += d0.w;
+        acc1.x += d1.x; acc1.y += d1.y; acc1.z += d1.z; acc1.w += d1.w;
+    }
+    // virtual slot v = 128 w + 64 h + lane holds the sum of channel quad v & (q - 1) (block-invariant: 512 % q == 0)
+    sm[128 * w + lane] = acc0;
+    sm[128 * w + 64 + lane] = acc1;
+    __syncthreads();
+    if ((int)threadIdx.x < q) {
+        float4 s = sm[threadIdx.x];
+        for (int k = threadIdx.x + q; k < 512; k += q) { const float4 v = sm[k]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * q * 4 + threadIdx.x * 4) = s;
+    }
+}
+
+// which window element gets the gradient, as 4 one-hot bits (0 when the maximum is not positive)
+__device__ __forceinline__ unsigned route_bits(float y0, float y1, float y2, float y3, float& m) {
+    m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+    const unsigned sel = y0 == m ? 0x1u : (y1 == m ? 0x10u : (y2 == m ? 0x100u : 0x1000u));
+    return m > 0.f ? sel : 0u;
+}
+
+__global__ __launch_bounds__(256) void bias_relu_pool_forward_bits_kernel(const float4* __restrict__ y, const float* __restrict__ bias,
+                                                                          float4* __restrict__ p, unsigned short* __restrict__ mask,
+                                                                          size_t nq, int Hp, int Wp, int q) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float4 b = *reinterpret_cast<const float4*>(bias + (int)(t % (size_t)q) * 4);
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t rowq = (size_t)2 * Wp * q;
+    for (size_t i = t; i < nq; i += stride) {
+        const size_t pix = i / q; const int cq = (int)(i - pix * q);
+        const size_t n_i = pix / Wp; const int j = (int)(pix - n_i * Wp);
+        const size_t base = (n_i * 2) * rowq + (size_t)(2 * j) * q + cq;
+        const float4 a0 = relu_bias4(y[base], b), a1 = relu_bias4(y[base + q], b);
+        const float4 a2 = relu_bias4(y[base + rowq], b), a3 = relu_bias4(y[base + rowq + q], b);
+        float4 m;
+        const unsigned bits = route_bits(a0.x, a1.x, a2.x, a3.x, m.x) | route_bits(a0.y, a1.y, a2.y, a3.y, m.y) << 1 |
+                              route_bits(a0.z, a1.z, a2.z, a3.z, m.z) << 2 | route_bits(a0.w, a1.w, a2.w, a3.w, m.w) << 3;
+        p[i] = m;
+        if (mask) mask[i] = (unsigned short)bits;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_relu_pool_backward_bits_kernel(const unsigned short* __restrict__ mask,
+                                                                           const float4* __restrict__ gp, float4* __restrict__ g,
+                                                                           float* __restrict__ partial, size_t nq, int Hp, int Wp,
+                                                                           int q) {
+    __shared__ float4 sm[256];
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t rowq = (size_t)2 * Wp * q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = t; i < nq; i += stride) {
+        const size_t pix = i / q; const int cq = (int)(i - pix * q);
+        const size_t n_i = pix / Wp; const int j = (int)(pix - n_i * Wp);
+        const size_t base = (n_i * 2) * rowq + (size_t)(2 * j) * q + cq;
+        const unsigned bits = mask[i];
+        const float4 d = gp[i];
+        g[base] = keep4(d, bits); g[base + q] = keep4(d, bits >> 4);
+        g[base + rowq] = keep4(d, bits >> 8); g[base + rowq + q] = keep4(d, bits >> 12);
+        // exactly one window element (or none) holds d: the window's contribution to db is d where any bit of the component is set
+        const float4 live = keep4(d, (bits | bits >> 4 | bits >> 8 | bits >> 12) & 15u);
+        acc.x += live.x; acc.y += live.y; acc.z += live.z; acc.w += live.w;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < q) {
+        float4 s = sm[threadIdx.x];
+        for (int k = threadIdx.x + q; k < 256; k += q) { const float4 v = sm[k]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * q * 4 + threadIdx.x * 4) = s;
+    }
+}
+
+// grid of the chunked (two float4 per lane) kernels: one wave per 128 float4, at most EPI_BLOCKS blocks
+static unsigned epi_grid2(size_t n4) {
+    const size_t g = (n4 + 511) / 512;
+    return (unsigned)(g < 1 ? 1 : (g > (size_t)EPI_BLOCKS ? (size_t)EPI_BLOCKS : g));
+}
+
 static unsigned epi_grid(size_t n4) {
     const size_t g = (n4 + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > (size_t)EPI_BLOCKS ? (size_t)EPI_BLOCKS : g));
@@ -232,6 +367,77 @@ extern "C" int uh_bias_relu_pool_backward(const float* y, const float* gpooled, 
     const unsigned grid = epi_grid(nq);
     hipStream_t s = (hipStream_t)stream;
     launch_timed(UH_K_EPI_BWD, bias_relu_pool_backward_kernel, dim3(grid), dim3(256), s, reinterpret_cast<const float4*>(y),
+                 reinterpret_cast<const float4*>(gpooled), reinterpret_cast<float4*>(g), (float*)workspace, nq, H / 2, W / 2, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
+    return (int)hipGetLastError();
+}
+
+
+// ---- bit-mask variants (see the kernels): the backward reads gy + 1 bit per element instead of gy + y --------------------
+extern "C" size_t uh_relu_mask_bytes(size_t npix, int C) {
+    if (check_epi(npix, C)) return 0;
+    return ((npix * (size_t)C / 4 + 127) / 128) * 64;
+}
+
+extern "C" int uh_bias_relu_forward_bits(float* y, const float* bias, void* mask, size_t npix, int C, uh_stream_t stream) {
+    if (!y || !bias || !mask) return UH_E_NULL;
+    if (int e = check_epi(npix, C)) return e;
+    const size_t n4 = npix * (size_t)C / 4;
+    launch_timed(UH_K_EPI_FWD, bias_relu_forward_bits_kernel, dim3(epi_grid2(n4)), dim3(256), (hipStream_t)stream,
+                 reinterpret_cast<float4*>(y), bias, (unsigned char*)mask, n4, C / 4);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t uh_bias_relu_backward_bits_workspace_bytes(size_t npix, int C) {
+    if (check_epi(npix, C)) return 0;
+    return (size_t)epi_grid2(npix * (size_t)C / 4) * C * sizeof(float);
+}
+
+extern "C" int uh_bias_relu_backward_bits(const void* mask, const float* gy, float* g, float* dbias, void* workspace,
+                                          size_t workspace_bytes, size_t npix, int C, uh_stream_t stream) {
+    if (!mask || !gy || !g || !dbias) return UH_E_NULL;
+    if (int e = check_epi(npix, C)) return e;
+    if (!workspace || workspace_bytes < uh_bias_relu_backward_bits_workspace_bytes(npix, C)) return UH_E_WORKSPACE;
+    const size_t n4 = npix * (size_t)C / 4;
+    const unsigned grid = epi_grid2(n4);
+    hipStream_t s = (hipStream_t)stream;
+    launch_timed(UH_K_EPI_BWD, bias_relu_backward_bits_kernel, dim3(grid), dim3(256), s, (const unsigned char*)mask,
+                 reinterpret_cast<const float4*>(gy), reinterpret_cast<float4*>(g), (float*)workspace, n4, C / 4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t uh_pool_mask_bytes(int N, int H, int W, int C) {
+    if (check_pool(N, H, W, C)) return 0;
+    return (size_t)N * (H / 2) * (W / 2) * (C / 4) * sizeof(unsigned short);
+}
+
+extern "C" int uh_bias_relu_pool_forward_bits(const float* y, const float* bias, float* pooled, void* mask, int N, int H, int W,
+                                              int C, uh_stream_t stream) {
+    if (!y || !bias || !pooled) return UH_E_NULL;                 // mask may be NULL: forward only (no backward will follow)
+    if (int e = check_pool(N, H, W, C)) return e;
+    const int q = C / 4;
+    const size_t nq = (size_t)N * (H / 2) * (W / 2) * q;
+    launch_timed(UH_K_EPI_FWD, bias_relu_pool_forward_bits_kernel, dim3(epi_grid(nq)), dim3(256), (hipStream_t)stream,
+                 reinterpret_cast<const float4*>(y), bias, reinterpret_cast<float4*>(pooled), (unsigned short*)mask, nq, H / 2,
+                 W / 2, q);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uh_bias_relu_pool_backward_bits(const void* mask, const float* gpooled, float* g, float* dbias, void* workspace,
+                                               size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream) {
+    if (!mask || !gpooled || !g || !dbias) return UH_E_NULL;
+    if (int e = check_pool(N, H, W, C)) return e;
+    if (!workspace || workspace_bytes < uh_bias_relu_pool_backward_workspace_bytes(N, H, W, C)) return UH_E_WORKSPACE;
+    const int q = C / 4;
+    const size_t nq = (size_t)N * (H / 2) * (W / 2) * q;
+    const unsigned grid = epi_grid(nq);
+    hipStream_t s = (hipStream_t)stream;
+    launch_timed(UH_K_EPI_BWD, bias_relu_pool_backward_bits_kernel, dim3(grid), dim3(256), s, (const unsigned short*)mask,
                  reinterpret_cast<const float4*>(gpooled), reinterpret_cast<float4*>(g), (float*)workspace, nq, H / 2, W / 2, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

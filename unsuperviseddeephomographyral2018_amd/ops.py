@@ -659,9 +659,53 @@ class _ConvBiasReLU(torch.autograd.Function):
         return dx, dw, (db if ctx.needs_input_grad[2] else None), None
 
 
+class _ConvBiasReLUBits(torch.autograd.Function):
+    """_ConvBiasReLU with the backward's ReLU mask kept as one bit per element (uh_bias_relu_forward_bits): the backward reads
+    gy + bits instead of gy + y (12 -> 8 B/element)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding):
+        lib = _lib.load()
+        y = torch.nn.functional.conv2d(x, weight, None, 1, padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        N, Cc, Hh, Ww = y.shape
+        mask = torch.empty((lib.uh_relu_mask_bytes(N * Hh * Ww, Cc),), dtype=torch.uint8, device=y.device)
+        _lib.check(lib.uh_bias_relu_forward_bits(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(mask), N * Hh * Ww, Cc, _stream()),
+                   'uh_bias_relu_forward_bits')
+        ctx.save_for_backward(x, weight, mask)
+        ctx.padding, ctx.shape = padding, (N, Cc, Hh, Ww)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, weight, mask = ctx.saved_tensors
+        N, Cc, Hh, Ww = ctx.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        g = torch.empty_like(gy, memory_format=torch.channels_last)
+        db = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
+        npix = N * Hh * Ww
+        nbytes = lib.uh_bias_relu_backward_bits_workspace_bytes(npix, Cc)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=gy.device)
+        _lib.check(lib.uh_bias_relu_backward_bits(_ptr(mask), _ptr(gy), _ptr(g), _ptr(db), _ptr(ws), nbytes, npix, Cc, _stream()),
+                   'uh_bias_relu_backward_bits')
+        p = ctx.padding
+        dx, dw, _ = torch.ops.aten.convolution_backward(
+            g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
+
+
+def _epi_bits():
+    """UH_EPI_BITS=0: the round 1-5 epilogues (the backward re-reads the activation); default: the bit-mask epilogues."""
+    import os
+    return os.environ.get('UH_EPI_BITS', '1') != '0'
+
+
 def conv_bias_relu(x, weight, bias, padding=1):
     """relu(conv2d(x, weight, bias, stride 1, padding)) -- homography_model.py:88-95 (_conv2d without batch norm)."""
-    return _ConvBiasReLU.apply(x, weight, bias, padding)
+    return (_ConvBiasReLUBits if _epi_bits() else _ConvBiasReLU).apply(x, weight, bias, padding)
 
 
 class _ConvBiasReLUPool(torch.autograd.Function):
@@ -702,6 +746,48 @@ class _ConvBiasReLUPool(torch.autograd.Function):
         return dx, dw, (db if ctx.needs_input_grad[2] else None), None
 
 
+class _ConvBiasReLUPoolBits(torch.autograd.Function):
+    """_ConvBiasReLUPool with the routing of the pooled gradient kept as 4 bits per pooled element: relu(conv + b) is never
+    written back at full resolution (the conv output is released right after the forward) and the backward reads
+    gpooled + bits (9 -> 5 B per conv-output element each way)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding):
+        lib = _lib.load()
+        y = torch.nn.functional.conv2d(x, weight, None, 1, padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        N, Cc, Hh, Ww = y.shape
+        pooled = torch.empty((N, Cc, Hh // 2, Ww // 2), dtype=torch.float32, device=y.device,
+                             memory_format=torch.channels_last)
+        need_bw = any(ctx.needs_input_grad[:3])
+        mask = torch.empty((lib.uh_pool_mask_bytes(N, Hh, Ww, Cc),), dtype=torch.uint8, device=y.device) if need_bw else None
+        _lib.check(lib.uh_bias_relu_pool_forward_bits(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(pooled), _ptr(mask), N, Hh, Ww, Cc,
+                                                      _stream()), 'uh_bias_relu_pool_forward_bits')
+        if need_bw:
+            ctx.save_for_backward(x, weight, mask)
+        ctx.padding, ctx.shape = padding, (N, Cc, Hh, Ww)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gp):
+        lib = _lib.load()
+        x, weight, mask = ctx.saved_tensors
+        N, Cc, Hh, Ww = ctx.shape
+        gp = gp.contiguous(memory_format=torch.channels_last)
+        g = torch.empty((N, Cc, Hh, Ww), dtype=torch.float32, device=gp.device, memory_format=torch.channels_last)
+        db = torch.empty((Cc,), dtype=torch.float32, device=gp.device)
+        nbytes = lib.uh_bias_relu_pool_backward_workspace_bytes(N, Hh, Ww, Cc)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=gp.device)
+        _lib.check(lib.uh_bias_relu_pool_backward_bits(_ptr(mask), _ptr(gp), _ptr(g), _ptr(db), _ptr(ws), nbytes, N, Hh, Ww, Cc,
+                                                       _stream()), 'uh_bias_relu_pool_backward_bits')
+        p = ctx.padding
+        dx, dw, _ = torch.ops.aten.convolution_backward(
+            g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
+
+
 def conv_bias_relu_pool(x, weight, bias, padding=1):
     """max_pool2d(relu(conv2d(x, weight, bias)), 2, 2) -- _conv2d + _maxpool2d (homography_model.py:88-105); H, W even."""
-    return _ConvBiasReLUPool.apply(x, weight, bias, padding)
+    return (_ConvBiasReLUPoolBits if _epi_bits() else _ConvBiasReLUPool).apply(x, weight, bias, padding)
