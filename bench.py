@@ -76,7 +76,7 @@ def parse():
                          '--pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (separate passes) after the headline; 0: read the committed file')
     ap.add_argument('--traffic_child', type=int, default=0, help='(internal) this process is one of those child runs')
     ap.add_argument('--quality', type=int, default=1, help='0: skip the mean-corner-error training run')
-    ap.add_argument('--quality_steps', type=int, default=8000, help='training steps of the quality run (~5.6 ms each)')
+    ap.add_argument('--quality_steps', type=int, default=8000, help='training steps of the quality run')
     ap.add_argument('--quality_pool', type=int, default=384, help='in-HBM pool of pre-generated training batches (118 MB each)')
     ap.add_argument('--quality_texture', default='multiscale', choices=['smooth', 'multiscale'])
     ap.add_argument('--cpu_sample_pairs', type=int, default=64, help='CPU leg: batch size (default = the GPU batch)')
@@ -345,7 +345,7 @@ def library_fingerprint():
         return uh_build._fingerprint()
 
 
-TRAFFIC_FILES = ('traffic_r05.json', 'traffic_r04.json', 'traffic_r03.json', 'traffic_r02.json', 'traffic_r01.json')
+TRAFFIC_FILES = ('traffic_r06.json', 'traffic_r05.json', 'traffic_r04.json', 'traffic_r03.json', 'traffic_r02.json', 'traffic_r01.json')
 
 
 def committed_traffic(key):
@@ -615,7 +615,8 @@ def main():
         def run_steps(n):
             for _ in range(n):
                 step_fn(batch)
-        exchange = uh_dist.exchange_report(step_fn.averager, run_steps, float(tt.item()) / args.steps * 1e3)
+        exchange = uh_dist.exchange_report(step_fn.averager, run_steps, float(tt.item()) / args.steps * 1e3,
+                                            resync=(step_fn.net, step_fn.opt))
     dt = float(tt.item())
     if rank != 0:
         if world > 1:
@@ -679,10 +680,16 @@ def main():
                                 'flops_per_step': step_flops,
                                 'note': 'whole train step (3 x forward FLOPs of the VGG regressor x global batch) / ms_per_step against the f32-input '
                                         'MFMA peak per GPU (v_mfma_f32_32x32x2_f32 = the f32 vector rate; gfx950 has no xf32 / TF32): the conv '
-                                        'stack is stock MIOpen by north_star, the hand-written hot path is 1.5 % of the step'}
+                                        'stack is stock MIOpen by north_star; hot_path_share_of_step = the library kernels timed in this run '
+                                        '(roofline.kernels: avg_us x launches / steps) over ms_per_step; per-kernel step anatomy: '
+                                        'profiles/r06_step_breakdown.txt'}
+    if kern:
+        timed_us = sum(v['avg_us'] * v['launches'] for v in kern.values()) / max(args.steps, 1)
+        out['headline_roofline']['hot_path_share_of_step'] = round(timed_us / (dt / args.steps * 1e6), 4)
+        out['headline_roofline']['hot_path_kernels_timed'] = sorted(kern)
     out['config']['warmup_seconds'] = round(warmup_s, 1)
-    out['config']['tunable_gemm'] = ('on: torch.cuda.tunable picked the fully connected GEMMs (fc1 forward 142 -> 55 us; --tunable_gemm 0 = rounds 1-3)'
-                                     if tuned_gemms else 'off')
+    out['config']['tunable_gemm'] = ('on: torch.cuda.tunable picked the fully connected GEMMs (A/B: profiles/r04_tunable_gemm_ab.jsonl; '
+                                     '--tunable_gemm 0 = the library heuristic)' if tuned_gemms else 'off')
     out['config']['miopen_find'] = ('cudnn.benchmark = True; reference solvers excluded from the trials '
                                     '(MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD/BWD/WRW=%s)' % os.environ.get('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'))
     if other_law is not None and isinstance(out.get('roofline'), dict):
@@ -694,10 +701,10 @@ def main():
             span = max(temps['cold_us'] - temps['warm_us'], 1e-9)
             temps['in_step_position_between_warm_and_cold'] = round((t_in - temps['warm_us']) / span, 3)
             temps['reading'] = ('the in-step launch (%.1f us) lies %.0f %% of the way from the same launch back to back (warm, %.1f us: U served '
-                                'by the Infinity Cache) to the same launch after a 1 GiB evicting copy (cold, %.1f us): the gap between '
-                                'roofline.frac and the warm figure is COLD INPUT, not grid tail -- t(B) over B = 32..128 is a straight line '
-                                '(profiles/r04_cold_forward.jsonl: residuals <= 0.4 us; cold: fixed 9.5 us + 0.295 us/pair = 0.78 x 8 TB/s '
-                                'asymptotically, the float4-copy yardstick; the fixed part is a third of this launch)'
+                                'by the Infinity Cache) to the same launch after a 1 GiB evicting copy (cold, %.1f us), all three measured in '
+                                'this run.  What the cold launch is made of (dispatch overhead, the drain after the last block is '
+                                'dispatched, XCDs finishing apart): profiles/r05_launch_anatomy.jsonl, profiles/r05_launch_anatomy_tail.jsonl, '
+                                'profiles/r05_pmc_cold_warm.jsonl; batch sweep: profiles/r04_cold_forward.jsonl'
                                 % (t_in, 100.0 * (t_in - temps['warm_us']) / span, temps['warm_us'], temps['cold_us']))
         out['roofline']['why_in_step_frac_is_below_the_warm_point'] = temps
     if world > 1:
@@ -740,11 +747,10 @@ def main():
         del step_fn, model
         torch.cuda.empty_cache()
         out['quality'] = guarded(quality_run, device, args)
-    out['timing_note'] = ('per-dispatch HIP events on the warp kernels inside the timed region (--profile 1) cost a small pipeline '
-                          'bubble each: the headline is understated by ~0.3 % (measured with --profile 0).  Since round 4 the events are '
-                          'created with hipEventDisableSystemFence: a default event writes back and invalidates the caches when it completes, '
-                          'which made rounds 1-3 read the in-step forward ~1 us and the sparse backward ~1.4 us too long '
-                          '(UH_PROF_FENCE=1 restores that; profiles/r04_prefetch_ab_library_side_stream.jsonl)') if args.profile else None
+    out['timing_note'] = ('per-dispatch HIP events on the warp kernels inside the timed region (--profile 1) cost a small pipeline bubble '
+                          'each; --profile 0 gives the headline without them.  The events are created with hipEventDisableSystemFence (a '
+                          'default event writes back and invalidates the caches when it completes and lengthens the launches it '
+                          'brackets; UH_PROF_FENCE=1 restores that; A/B: profiles/r04_prefetch_ab_library_side_stream.jsonl)') if args.profile else None
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

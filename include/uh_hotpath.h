@@ -108,7 +108,8 @@ UH_API int uh_dlt_backward(const float* pts1, const float* h4p, const float* H,
  * this so that the guard is never silent).  SYNCHRONOUS on `stream` (only): a one-thread kernel ordered after the work
  * already enqueued there takes the count -- and with reset != 0 clears it -- in one atomic exchange, so no increment is
  * lost between the read and the clear; launches still pending on other streams are counted by the next call.
- * UH_E_CAPTURING when `stream` is being captured (call it at log time, outside any capture).                         */
+ * UH_E_CAPTURING when `stream` is being captured, or is the NULL stream while a blocking capture is open (call it at log
+ * time, outside any capture).  Concurrent callers are serialised inside (the take passes through one device word).       */
 UH_API int uh_dlt_zeroed_pairs(unsigned long long* count, int reset, uh_stream_t stream);
 
 /* ---- Spatial transformer ----------------------------------------------------------------------
@@ -245,37 +246,27 @@ UH_API void   uh_tail_destroy(uh_tail_plan* plan);
 
 /* ---- bias + ReLU epilogue of the regressor's conv layers (outside the reference's hot path; conv GEMMs stay MIOpen) --
  * y [npix, C] NHWC activation (npix = N*H*W), C % 4 == 0 and 1024 % C == 0.   homography_model.py:88-95 (_conv2d)
- *   forward : y <- max(y + bias[c], 0) in place
- *   backward: g = (y > 0) ? gy : 0 ; dbias[c] = sum g     (deterministic two-stage reduction through `workspace`)      */
-UH_API int    uh_bias_relu_forward(float* y, const float* bias, size_t npix, int C, uh_stream_t stream);
+ *   forward : y <- max(y + bias[c], 0) in place; mask <- one bit per element (y > 0) for the backward
+ *   backward: g = bit ? gy : 0 ; dbias[c] = sum g          (deterministic two-stage reduction through `workspace`)
+ * The backward reads gy + BITS, not the activation (ABI 8; ABI <= 7 re-read y).  `mask` is opaque: uh_relu_mask_bytes /
+ * uh_pool_mask_bytes bytes, written by the forward and consumed by the backward of the SAME shape.  Both forwards accept
+ * mask == NULL (forward only: no backward will follow).                                                              */
+UH_API size_t uh_relu_mask_bytes(size_t npix, int C);
+UH_API int    uh_bias_relu_forward(float* y, const float* bias, void* mask, size_t npix, int C, uh_stream_t stream);
 UH_API size_t uh_bias_relu_backward_workspace_bytes(size_t npix, int C);
-UH_API int    uh_bias_relu_backward(const float* y, const float* gy, float* g, float* dbias, void* workspace,
+UH_API int    uh_bias_relu_backward(const void* mask, const float* gy, float* g, float* dbias, void* workspace,
                              size_t workspace_bytes, size_t npix, int C, uh_stream_t stream);
 
-/* the same fused with the 2x2/2 max-pool that follows (homography_model.py:102-105): y [N,H,W,C] (H, W even) is
- * rewritten in place with relu(y + b) and kept for the backward; pooled / gpooled [N,H/2,W/2,C].                      */
-UH_API int    uh_bias_relu_pool_forward(float* y, const float* bias, float* pooled, int N, int H, int W, int C,
-                                 uh_stream_t stream);
-UH_API size_t uh_bias_relu_pool_backward_workspace_bytes(int N, int H, int W, int C);
-UH_API int    uh_bias_relu_pool_backward(const float* y, const float* gpooled, float* g, float* dbias, void* workspace,
-                                  size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream);
-
-/* bit-mask variants: the forward keeps ONE BIT per element for the backward instead of the activation itself (ReLU: y > 0;
- * pool: which window element receives the gradient, none when the window maximum is not positive), so the backward reads
- * gy + bits instead of gy + y, and the pooled forward does not write relu(y + b) back at full resolution (nothing downstream
- * reads it: the next conv consumes `pooled`).  `mask` is opaque: uh_relu_mask_bytes / uh_pool_mask_bytes bytes, produced by
- * the forward and consumed by the backward of the SAME shape.  uh_bias_relu_pool_forward_bits accepts mask == NULL
- * (forward only) and leaves y untouched.                                                                              */
-UH_API size_t uh_relu_mask_bytes(size_t npix, int C);
-UH_API int    uh_bias_relu_forward_bits(float* y, const float* bias, void* mask, size_t npix, int C, uh_stream_t stream);
-UH_API size_t uh_bias_relu_backward_bits_workspace_bytes(size_t npix, int C);
-UH_API int    uh_bias_relu_backward_bits(const void* mask, const float* gy, float* g, float* dbias, void* workspace,
-                                  size_t workspace_bytes, size_t npix, int C, uh_stream_t stream);
+/* the same fused with the 2x2/2 max-pool that follows (homography_model.py:102-105): y [N,H,W,C] (H, W even) is only READ
+ * (relu(y + b) is never written back at full resolution: the next conv consumes `pooled`); pooled / gpooled [N,H/2,W/2,C];
+ * mask <- per pooled element, which of its four window elements receives the gradient (the first maximum, as max_pool2d;
+ * none when the maximum is not positive).                                                                             */
 UH_API size_t uh_pool_mask_bytes(int N, int H, int W, int C);
-UH_API int    uh_bias_relu_pool_forward_bits(const float* y, const float* bias, float* pooled, void* mask, int N, int H,
-                                      int W, int C, uh_stream_t stream);
-UH_API int    uh_bias_relu_pool_backward_bits(const void* mask, const float* gpooled, float* g, float* dbias, void* workspace,
-                                       size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream);
+UH_API int    uh_bias_relu_pool_forward(const float* y, const float* bias, float* pooled, void* mask, int N, int H, int W,
+                                 int C, uh_stream_t stream);
+UH_API size_t uh_bias_relu_pool_backward_workspace_bytes(int N, int H, int W, int C);
+UH_API int    uh_bias_relu_pool_backward(const void* mask, const float* gpooled, float* g, float* dbias, void* workspace,
+                                  size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream);
 
 /* ---- in-library kernel timing (used by bench.py for the roofline figure) -----------------------------
  * When enabled, every launch above is bracketed by hipEventRecord on ITS stream; uh_profile_read()

@@ -107,11 +107,11 @@ def test_argument_errors_without_gpu(uh_lib_path):
     assert lib.uh_prepare_inputs(*args13, 0, 8, 8, 4, None) == -2
     assert lib.uh_prepare_inputs(*args13, 2, 8, 8, 16, None) == -2                                  # patch larger than frame
     assert lib.uh_prepare_inputs(None, *args13[1:], 2, 8, 8, 4, None) == -1
-    assert lib.uh_bias_relu_forward(one, one, 100, 6, None) == -3                                    # C % 4 != 0
-    assert lib.uh_bias_relu_forward(one, one, 100, 96, None) == -3                                   # 1024 % C != 0
-    assert lib.uh_bias_relu_forward(one, None, 100, 64, None) == -1
+    assert lib.uh_bias_relu_forward(one, one, one, 100, 6, None) == -3                                    # C % 4 != 0
+    assert lib.uh_bias_relu_forward(one, one, one, 100, 96, None) == -3                                   # 1024 % C != 0
+    assert lib.uh_bias_relu_forward(one, None, one, 100, 64, None) == -1
     assert lib.uh_bias_relu_backward(one, one, one, one, None, 0, 100, 64, None) == -4
-    assert lib.uh_bias_relu_pool_forward(one, one, one, 2, 7, 8, 64, None) == -2                     # odd height
+    assert lib.uh_bias_relu_pool_forward(one, one, one, one, 2, 7, 8, 64, None) == -2                     # odd height
     assert lib.uh_bias_relu_pool_backward_workspace_bytes(2, 7, 8, 64) == 0
     plan = C.c_void_p()
     assert lib.uh_tail_create(C.byref(plan), 4, 60, 80, 3, 128, 0) == -2                             # patch larger than frame

@@ -149,7 +149,7 @@ def test_regressor_flops_match_the_survey(bench):
     assert bench.regressor_flops(64) < bench.regressor_flops(128) / 3.9
 
 
-EVIDENCE_ROUND = 'r05'        # the round whose profiles/ evidence must have been taken on the kernel sources in the tree
+EVIDENCE_ROUND = 'r06'        # the round whose profiles/ evidence must have been taken on the kernel sources in the tree
 
 
 def test_committed_evidence_was_measured_on_the_current_kernel_sources():
@@ -165,3 +165,31 @@ def test_committed_evidence_was_measured_on_the_current_kernel_sources():
     assert tr['_fingerprint'] == fp
     for name in ('%s_bench_kernel_stats_timed_steps.csv' % EVIDENCE_ROUND, '%s_step_breakdown.txt' % EVIDENCE_ROUND):
         assert read_fingerprint(os.path.join(ROOT, 'profiles', name)) == fp, name
+
+
+def test_bench_source_holds_no_frozen_measurements():
+    """the bench line carries what the run measured and file pointers, not prose with numbers somebody measured
+    once ("fc1 forward 142 -> 55 us", "the hot path is 1.5 % of the step").  Checked on the SOURCE: no string literal of bench.py
+    outside docstrings holds a literal number followed by a measurement unit -- numbers reach the line through format specifiers
+    fed by variables.  Allowed: the constants of a definition (the theta law N(0, 2 px))."""
+    import ast
+    import re
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    tree = ast.parse(src)
+    docstrings = set()
+    for n in ast.walk(tree):
+        if isinstance(n, (ast.FunctionDef, ast.Module, ast.ClassDef)) and n.body and isinstance(n.body[0], ast.Expr) \
+                and isinstance(n.body[0].value, ast.Constant) and isinstance(n.body[0].value.value, str):
+            docstrings.add(id(n.body[0].value))
+    unit = re.compile(r'(?<![%\w.])(\d+(?:[ .]\d+)*)\s*(us|\u00b5s|ms|%|px|pairs/s|GB/s|TB/s|TFLOP/s)(?![\w/])')
+    allowed = {'2 px', '2px'}
+    found = []
+    for n in ast.walk(tree):
+        if isinstance(n, ast.Constant) and isinstance(n.value, str) and id(n) not in docstrings:
+            found += [(n.lineno, m.group(0)) for m in unit.finditer(n.value) if m.group(0) not in allowed]
+    assert not found, 'literal measurements in bench.py strings (use a variable or a profiles/ pointer): %r' % found
+    # every profiles/ file the line points at exists
+    for f in set(re.findall(r'profiles/[\w./-]+\.(?:jsonl|json|txt|csv)', src)):
+        if '%' in f or 'rNN' in f or f.startswith('profiles/r06_'):             # round-6 evidence is written by the GPU session of this round
+            continue
+        assert os.path.exists(os.path.join(ROOT, f)), f

@@ -384,7 +384,10 @@ def test_mode_picks_joint_or_disjoint_and_the_apply_rule_is_u_gt_one_minus_p(tmp
     prm0 = prm._replace(do_augment=0.0)
     next(dl.Dataloader(prm0, shuffle=False, device='cpu').stream())
     assert seen['aug'] is None                                               # do_augment 0: the kernel's un-augmented instantiation
-    # (3) the test driver asks for mode 'test' (disjoint), unshuffled, with the user's do_augment (homography_CNN_synthetic.py:138-148)
+    # (3) the test driver asks for mode 'test' (disjoint) with the user's do_augment (homography_CNN_synthetic.py:138-148).  The
+    # reference builds that loader with shuffle=True (:404, under a comment that says "No shuffle"); walking the list in order is
+    # THIS driver's deliberate default (reproducible statistics, every pair exactly three times), not parity: --test_shuffle True
+    # gives the reference's shuffled stream
     got = {}
 
     class Stop(Exception):
@@ -400,4 +403,8 @@ def test_mode_picks_joint_or_disjoint_and_the_apply_rule_is_u_gt_one_minus_p(tmp
     with pytest.raises(Stop):
         t.run()
     assert got['prm'].mode == 'test' and got['prm'].do_augment == 0.5 and got['kw']['shuffle'] is False
+    args.test_shuffle = True
+    with pytest.raises(Stop):
+        drv.TestHomography(args, step_fn=SimpleNamespace(net=torch.nn.Linear(1, 1))).run()
+    assert got['kw']['shuffle'] is True
     assert got['prm'].filenames_file == ff and got['prm'].augment_list == ['normalize']

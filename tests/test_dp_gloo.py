@@ -119,6 +119,67 @@ def _run_world2(backend):
     assert abs(out[0][2] - out[1][2]) < 1e-7
 
 
+def _worker_resync(rank, world, port, q):
+    """exchange_report's no-exchange steps are real optimizer steps on per-tower gradients: the replicas diverge.  With
+    resync=(module, optimizer) every rank leaves the call holding rank 0's variables and Adam state."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    D.init_from_env(backend='gloo')
+    torch.manual_seed(0)
+    net = Tiny()
+    for p in net.parameters():
+        torch.distributed.broadcast(p.data, src=0)
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(8, 2, 8, 8, generator=g); Y = torch.randn(8, 8, generator=g)
+    avg = D.GradAverager(net, world)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+
+    def run_steps(n):
+        for _ in range(n):
+            avg.reset()
+            ((net(D.shard(X, rank, world)) - D.shard(Y, rank, world)) ** 2).mean().backward()
+            avg.finish()
+            opt.step()
+    run_steps(2)                                                # averaged steps: replicas in step
+
+    def gathered():
+        flat = torch.cat([p.detach().flatten() for p in net.parameters()]
+                         + [opt.state[p][k].flatten().float() for p in net.parameters() for k in ('exp_avg', 'exp_avg_sq', 'step')])
+        both = [torch.empty_like(flat) for _ in range(world)]
+        torch.distributed.all_gather(both, flat)
+        return both
+    a, b = gathered()
+    in_step_before = bool(torch.equal(a, b))
+    rep_plain = D.exchange_report(avg, run_steps, ms_per_step=5.0, steps_without=2, bucket_iters=1)      # destructive form
+    a, b = gathered()
+    diverged = not torch.equal(a, b)
+    rep = D.exchange_report(avg, run_steps, ms_per_step=5.0, steps_without=2, bucket_iters=1, resync=(net, opt))
+    a, b = gathered()
+    in_step_after = bool(torch.equal(a, b))
+    run_steps(1)                                                # and the exchange is back on: still in step after a real step
+    a, b = gathered()
+    q.put((rank, in_step_before, diverged, in_step_after, bool(torch.equal(a, b)), rep.get('resynced_tensors'),
+           'resynced_tensors' in rep_plain))
+    torch.distributed.destroy_process_group()
+
+
+def test_exchange_report_leaves_the_ranks_in_step():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_resync, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_tensors = 8 + 8 * 3                                       # 8 variables + (exp_avg, exp_avg_sq, step) each
+    for rank, before, diverged, after, after_step, nres, plain_has in out:
+        assert before and diverged and after and after_step, (rank, before, diverged, after, after_step)
+        assert nres == n_tensors and not plain_has
+
+
 def test_grad_averager_world1_and_alias_guard():
     from unsuperviseddeephomographyral2018_amd import dist as D
     torch.manual_seed(0)

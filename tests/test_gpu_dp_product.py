@@ -294,3 +294,71 @@ def test_product_step_over_rccl_one_rank_equals_plain_step():
     assert out['backend'] == 'nccl' and out['avg_identity'] and out['avg_in_collective']
     assert out['moved'] > 1e-4
     assert out['var_diff'][1] <= 1e-7 and out['var_diff'][0] <= 1e-5, out['var_diff']     # measured: (0.0, 0.0)
+
+
+def _train_worker(rank, world, port, q, tmp):
+    """train() itself on two gloo ranks sharing the GPU: 21 steps, --log_every 10."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), UH_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import contextlib
+    import io
+    import torch.distributed as dist
+    from unsuperviseddeephomographyral2018_amd import homography_CNN_synthetic as drv
+    seen = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        seen.append((str(t.dtype), int(t.numel())))
+        return real(t, *a, **k)
+    dist.all_reduce = counting
+    args = drv.build_parser().parse_args(
+        ['--mode', 'train', '--loss_type', 'l1_loss', '--batch_size', '8', '--num_gpus', '2', '--num_total_steps', '21',
+         '--log_every', '10', '--save_every', '1000', '--model_dir', os.path.join(tmp, 'models'), '--tunable_gemm', 'False',
+         '--seed', '5'])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        step_fn = drv.train(args)
+    flat = torch.cat([p.detach().flatten() for p in step_fn.net.parameters()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    q.put({'rank': rank, 'monitor_collectives': sum(1 for d, n in seen if d == 'torch.float64' and n == 14),
+           'small_f32_collectives': sum(1 for d, n in seen if d == 'torch.float32' and n <= 16),
+           'stdout': buf.getvalue(), 'in_step': bool(torch.equal(both[0], both[1])), 'global_step': step_fn.global_step})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_two_ranks_reduces_its_monitors_at_log_steps_only(tmp_path):
+    """train() at world 2: the six loss monitors are summed per rank and all-reduced ONLY at log steps (one
+    14-float collective at steps 0, 10, 20 of a 21-step run -- SURVEY 8e, reference :279-284,345-352), never per step; the final
+    line carries dist.exchange_report's object; and the extra no-exchange steps it runs leave no trace: both ranks hold the same
+    variables afterwards and the step counter says 21."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        out = sorted([q.get(timeout=900) for _ in range(world)], key=lambda o: o['rank'])
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    import json
+    for o in out:
+        assert o['monitor_collectives'] == 3, o['monitor_collectives']
+        assert o['small_f32_collectives'] == 0                      # the per-step 6-float mean of rounds 2-5 is gone
+        assert o['in_step'] and o['global_step'] == 21
+    log = out[0]['stdout']
+    assert log.count('Train: step') == 3 and 'Train: step 20' in log
+    line = [l for l in log.splitlines() if l.startswith('===> exchange (world 2, gloo): ')]
+    assert len(line) == 1
+    rep = json.loads(line[0].split(': ', 1)[1])
+    assert rep['ms_per_step_with_exchange'] > 0 and rep['ms_per_step_no_exchange'] > 0 and len(rep['buckets']) == 2
+    assert abs(rep['exchange_cost_ms_per_step'] - (rep['ms_per_step_with_exchange'] - rep['ms_per_step_no_exchange'])) < 2e-3
+    assert out[1]['stdout'].count('Train: step') == 0              # rank 0 alone prints

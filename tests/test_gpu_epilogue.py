@@ -1,4 +1,4 @@
-"""GPU: the conv epilogues that keep BITS for the backward (csrc/uh_epilogue.hip, *_bits entry points) through the C ABI, against
+"""GPU: the conv epilogues (csrc/uh_epilogue.hip: they keep BITS for the backward, not the activation) through the C ABI, against
 plain PyTorch f32 ops of the same function -- relu(y + b) and max_pool2d(relu(y + b), 2, 2) (homography_model.py:88-105) -- on
 every element, bit for bit (these are selections and copies: no tolerance), including exact ties inside pooling windows (first
 maximum wins, as max_pool2d), all-dead windows, NaN inputs, ragged sizes that end inside a 128-float4 chunk and every channel
@@ -55,27 +55,26 @@ def test_bias_relu_bits_forward_backward(lib, dev, npix, Cc):
     nmask = lib.uh_relu_mask_bytes(npix, Cc)
     assert nmask == ((npix * Cc // 4 + 127) // 128) * 64
     mask = torch.full((nmask + 64,), 0xAB, dtype=torch.uint8, device=dev)         # + guard bytes
-    _lib.check(lib.uh_bias_relu_forward_bits(_p(y), _p(bias), _p(mask), npix, Cc, _stream()), 'fwd')
+    _lib.check(lib.uh_bias_relu_forward(_p(y), _p(bias), _p(mask), npix, Cc, _stream()), 'fwd')
     assert torch.equal(y, ref)
     assert bool((mask[nmask:] == 0xAB).all())                                     # nothing written past the mask
-    nws = lib.uh_bias_relu_backward_bits_workspace_bytes(npix, Cc)
+    nws = lib.uh_bias_relu_backward_workspace_bytes(npix, Cc)
     outs = []
     for _ in range(2):
         ws = torch.empty(nws // 4, device=dev)
         gout = torch.full((npix, Cc), float('nan'), device=dev)
         db = torch.empty(Cc, device=dev)
-        _lib.check(lib.uh_bias_relu_backward_bits(_p(mask), _p(gy), _p(gout), _p(db), _p(ws), nws, npix, Cc, _stream()), 'bwd')
+        _lib.check(lib.uh_bias_relu_backward(_p(mask), _p(gy), _p(gout), _p(db), _p(ws), nws, npix, Cc, _stream()), 'bwd')
         outs.append((gout, db))
     want = torch.where(ref > 0, gy, torch.zeros_like(gy))
     assert torch.equal(outs[0][0], want)
     assert torch.equal(outs[0][1], outs[1][1])                                     # deterministic reduction
     dbw = want.double().sum(0)
     assert float((outs[0][1].double() - dbw).abs().max()) <= 1e-5 * max(1.0, float(want.abs().sum(0).max()))
-    # the activation-reading form gives the same g (and a db that differs only by summation order)
-    nws2 = lib.uh_bias_relu_backward_workspace_bytes(npix, Cc)
-    ws2 = torch.empty(nws2 // 4, device=dev); g2 = torch.empty_like(gy); db2 = torch.empty(Cc, device=dev)
-    _lib.check(lib.uh_bias_relu_backward(_p(y), _p(gy), _p(g2), _p(db2), _p(ws2), nws2, npix, Cc, _stream()), 'bwd y')
-    assert torch.equal(g2, outs[0][0])
+    # forward only: no mask, same activation
+    y2 = y0.clone()
+    _lib.check(lib.uh_bias_relu_forward(_p(y2), _p(bias), None, npix, Cc, _stream()), 'fwd nomask')
+    assert torch.equal(y2, ref)
 
 
 @pytest.mark.parametrize('N,Hh,Ww,Cc,nan', [(1, 2, 2, 4, 0.0), (2, 6, 10, 8, 0.0), (3, 8, 8, 64, 0.0), (2, 14, 6, 128, 0.0),
@@ -99,14 +98,14 @@ def test_bias_relu_pool_bits_forward_backward(lib, dev, N, Hh, Ww, Cc, nan):
     nmask = lib.uh_pool_mask_bytes(N, Hh, Ww, Cc)
     assert nmask == N * (Hh // 2) * (Ww // 2) * (Cc // 4) * 2
     mask = torch.full((nmask + 64,), 0xAB, dtype=torch.uint8, device=dev)
-    _lib.check(lib.uh_bias_relu_pool_forward_bits(_p(y), _p(bias), _p(pooled), _p(mask), N, Hh, Ww, Cc, _stream()), 'pool fwd')
+    _lib.check(lib.uh_bias_relu_pool_forward(_p(y), _p(bias), _p(pooled), _p(mask), N, Hh, Ww, Cc, _stream()), 'pool fwd')
     assert torch.equal(pooled, pooled_ref.detach().permute(0, 2, 3, 1))
     same = (y == y0) | (torch.isnan(y) & torch.isnan(y0))
     assert bool(same.all())                                                        # the conv output is left untouched
     assert bool((mask[nmask:] == 0xAB).all())
     # forward only (no backward will follow): no mask, same pooled map
     pooled2 = torch.empty_like(pooled)
-    _lib.check(lib.uh_bias_relu_pool_forward_bits(_p(y), _p(bias), _p(pooled2), None, N, Hh, Ww, Cc, _stream()), 'pool fwd nomask')
+    _lib.check(lib.uh_bias_relu_pool_forward(_p(y), _p(bias), _p(pooled2), None, N, Hh, Ww, Cc, _stream()), 'pool fwd nomask')
     assert torch.equal(pooled2, pooled)
     nws = lib.uh_bias_relu_pool_backward_workspace_bytes(N, Hh, Ww, Cc)
     outs = []
@@ -114,49 +113,20 @@ def test_bias_relu_pool_bits_forward_backward(lib, dev, N, Hh, Ww, Cc, nan):
         ws = torch.empty(nws // 4, device=dev)
         gout = torch.full((N, Hh, Ww, Cc), float('nan'), device=dev)
         db = torch.empty(Cc, device=dev)
-        _lib.check(lib.uh_bias_relu_pool_backward_bits(_p(mask), _p(gp), _p(gout), _p(db), _p(ws), nws, N, Hh, Ww, Cc, _stream()),
+        _lib.check(lib.uh_bias_relu_pool_backward(_p(mask), _p(gp), _p(gout), _p(db), _p(ws), nws, N, Hh, Ww, Cc, _stream()),
                    'pool bwd')
         outs.append((gout, db))
     assert torch.equal(outs[0][0], g_ref)
     assert torch.equal(outs[0][1], outs[1][1])
     dbw = g_ref.double().sum((0, 1, 2))
     assert float((outs[0][1].double() - dbw).abs().max()) <= 1e-5 * max(1.0, float(g_ref.abs().sum((0, 1, 2)).max()))
-    # the activation-reading pair (in-place forward + backward from y) routes identically
-    y_old = y0.clone(); pooled_old = torch.empty_like(pooled)
-    _lib.check(lib.uh_bias_relu_pool_forward(_p(y_old), _p(bias), _p(pooled_old), N, Hh, Ww, Cc, _stream()), 'pool fwd y')
-    ws2 = torch.empty(nws // 4, device=dev); g2 = torch.empty_like(gout); db2 = torch.empty(Cc, device=dev)
-    _lib.check(lib.uh_bias_relu_pool_backward(_p(y_old), _p(gp), _p(g2), _p(db2), _p(ws2), nws, N, Hh, Ww, Cc, _stream()), 'pool bwd y')
-    assert torch.equal(pooled_old, pooled) and torch.equal(g2, outs[0][0])
 
 
-def test_bits_argument_errors(lib, dev):
+def test_epilogue_argument_errors(lib, dev):
     one = _p(torch.zeros(4096, device=dev))
     assert lib.uh_relu_mask_bytes(100, 6) == 0 and lib.uh_pool_mask_bytes(2, 7, 8, 64) == 0
-    assert lib.uh_bias_relu_forward_bits(one, one, None, 16, 64, None) == -1
-    assert lib.uh_bias_relu_forward_bits(one, one, one, 16, 96, None) == -3
-    assert lib.uh_bias_relu_backward_bits(one, one, one, one, None, 0, 16, 64, None) == -4
-    assert lib.uh_bias_relu_pool_forward_bits(one, one, one, one, 1, 3, 4, 64, None) == -2
-    assert lib.uh_bias_relu_pool_backward_bits(None, one, one, one, one, 1 << 20, 1, 4, 4, 64, None) == -1
-
-
-def test_regressor_gradients_bits_vs_activation_form(dev, monkeypatch, uh_lib_path):
-    """The whole regressor, forward + backward, with UH_EPI_BITS=1 and =0: same output bits, and the same gradient bits wherever
-    the reduction order is shared (conv weights: MIOpen consumes identical g tensors; biases differ by summation order only)."""
-    from unsuperviseddeephomographyral2018_amd import homography_model as hm
-    torch.manual_seed(3)
-    net = hm.VGGRegressor(64, dropout_p=0.0).to(dev).to(memory_format=torch.channels_last)
-    x = torch.randn(4, 64, 64, 2, device=dev)
-    res = []
-    for bits in ('1', '0'):
-        monkeypatch.setenv('UH_EPI_BITS', bits)
-        net.zero_grad(set_to_none=True)
-        o = net(x)
-        o.square().mean().backward()
-        res.append((o.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}))
-    assert torch.equal(res[0][0], res[1][0])
-    for n in res[0][1]:
-        a, b = res[0][1][n], res[1][1][n]
-        if n.endswith('bias') and n.startswith('convs'):
-            assert float((a - b).abs().max()) <= 1e-5 * max(1e-6, float(b.abs().max())), n
-        else:
-            assert float((a - b).abs().max()) <= 1e-6 * max(1e-6, float(b.abs().max())), n
+    assert lib.uh_bias_relu_forward(one, None, one, 16, 64, None) == -1
+    assert lib.uh_bias_relu_forward(one, one, one, 16, 96, None) == -3
+    assert lib.uh_bias_relu_backward(one, one, one, one, None, 0, 16, 64, None) == -4
+    assert lib.uh_bias_relu_pool_forward(one, one, one, one, 1, 3, 4, 64, None) == -2
+    assert lib.uh_bias_relu_pool_backward(None, one, one, one, one, 1 << 20, 1, 4, 4, 64, None) == -1

@@ -32,6 +32,15 @@ def test_every_kernel_of_the_library_is_listed(res):
     assert len(res) >= 100                                          # 105 at round 4: a template that stopped instantiating shows here
 
 
+def test_the_metadata_keys_the_budgets_read_are_present(res):
+    """build.kernel_resources stores None for a metadata key hipcc did not emit: a toolchain that renames
+    .vgpr_spill_count / .private_segment_fixed_size must fail HERE, not make the spill and scratch checks pass vacuously."""
+    missing = {k: [f for f in ('vgpr', 'sgpr', 'vgpr_spill', 'sgpr_spill', 'scratch_bytes', 'lds_bytes') if v[f] is None]
+               for k, v in res.items()}
+    missing = {k: f for k, f in missing.items() if f}
+    assert not missing, 'code-object metadata keys missing: %r' % missing
+
+
 def test_no_kernel_spills_or_uses_scratch(res):
     bad = {k: v for k, v in res.items()
            if v['vgpr_spill'] or v['sgpr_spill'] or v['scratch_bytes'] or v['dynamic_stack'] or v['agpr']}

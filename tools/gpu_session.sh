@@ -29,8 +29,6 @@
 #   train_disk[:STEPS:PAIRS]  the reference's schedule (150 000 steps) FROM JPEG FILES with augmentation 0.5 (tools/train_from_disk.py)
 #   conv_relu_probe aten::miopen_convolution_relu per conv shape against conv + the shipped bias/ReLU pass (tools/conv_relu_probe.py)
 #   cpu_threads     the CPU leg alone at 8 / 32 / 128 / 256 host threads
-#   epi_ab[:REPS]   conv-epilogue A/B in ONE session: REPS (default 3) alternating pairs of the bench line with UH_EPI_BITS=0 (the
-#                   backward re-reads the activation) and =1 (bit-mask epilogues); one warm-up run first (MIOpen find-db)
 mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
 TAG=$1; shift
 COMMIT=${UH_COMMIT:-unknown}
@@ -120,12 +118,6 @@ for l in open('gpurun_out/${TAG}_cold_forward_variants.jsonl'):
     d = json.loads(l); print(d['tag'], d['B'], d['law'], d['temp'], d['us'], d['frac'])
 PYEOF
             ;;
-    epi_ab) : > gpurun_out/${TAG}_epi_ab.jsonl
-            UH_EPI_BITS=1 timeout 400 $BENCH > /dev/null 2>&1      # find-db / TunableOp warm-up, not recorded
-            for rep in $(seq 1 ${A1:-3}); do for BITS in 0 1; do
-              UH_EPI_BITS=$BITS timeout 400 $BENCH 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'epi_bits': $BITS, 'rep': $rep, 'pairs_per_s': d['value'], 'ms_per_step': d['ms_per_step'], 'final_loss': d['config'].get('final_loss')}))" >> gpurun_out/${TAG}_epi_ab.jsonl
-            done; done
-            cat gpurun_out/${TAG}_epi_ab.jsonl ;;
     *) echo "unknown stage $NAME" ;;
   esac
 done

@@ -53,19 +53,14 @@ SIGNATURES = {
     'uh_tail_run': (_i, [_p] * 12 + [_p, _z, _p]),
     'uh_tail_stats': (_i, [_p, _p, _p]),
     'uh_tail_destroy': (None, [_p]),
-    'uh_bias_relu_forward': (_i, [_p, _p, _z, _i, _p]),
+    'uh_relu_mask_bytes': (_z, [_z, _i]),
+    'uh_bias_relu_forward': (_i, [_p, _p, _p, _z, _i, _p]),
     'uh_bias_relu_backward_workspace_bytes': (_z, [_z, _i]),
     'uh_bias_relu_backward': (_i, [_p, _p, _p, _p, _p, _z, _z, _i, _p]),
-    'uh_bias_relu_pool_forward': (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    'uh_pool_mask_bytes': (_z, [_i, _i, _i, _i]),
+    'uh_bias_relu_pool_forward': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'uh_bias_relu_pool_backward_workspace_bytes': (_z, [_i, _i, _i, _i]),
     'uh_bias_relu_pool_backward': (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
-    'uh_relu_mask_bytes': (_z, [_z, _i]),
-    'uh_bias_relu_forward_bits': (_i, [_p, _p, _p, _z, _i, _p]),
-    'uh_bias_relu_backward_bits_workspace_bytes': (_z, [_z, _i]),
-    'uh_bias_relu_backward_bits': (_i, [_p, _p, _p, _p, _p, _z, _z, _i, _p]),
-    'uh_pool_mask_bytes': (_z, [_i, _i, _i, _i]),
-    'uh_bias_relu_pool_forward_bits': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    'uh_bias_relu_pool_backward_bits': (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     'uh_profile_enable': (_i, [_i]),
     'uh_profile_read': (_i, [_p, _p]),
     'uh_kernel_name': (C.c_char_p, [_i]),

@@ -97,9 +97,11 @@ def kernel_resources(force=False):
         for k in ks:
             name = re.sub(r'\(.*$', '', dem[i]).replace('void ', '') or k['.name']
             i += 1
-            out[name] = {'file': src, 'vgpr': k.get('.vgpr_count', 0), 'agpr': k.get('.agpr_count', 0), 'sgpr': k.get('.sgpr_count', 0),
-                         'vgpr_spill': k.get('.vgpr_spill_count', 0), 'sgpr_spill': k.get('.sgpr_spill_count', 0),
-                         'scratch_bytes': k.get('.private_segment_fixed_size', 0), 'lds_bytes': k.get('.group_segment_fixed_size', 0),
+            # a key the toolchain did not emit is None (NOT 0): tests/test_kernel_resources.py must fail on it instead of reading
+            # "no spills" out of a renamed metadata field
+            out[name] = {'file': src, 'vgpr': k.get('.vgpr_count'), 'agpr': k.get('.agpr_count', 0), 'sgpr': k.get('.sgpr_count'),
+                         'vgpr_spill': k.get('.vgpr_spill_count'), 'sgpr_spill': k.get('.sgpr_spill_count'),
+                         'scratch_bytes': k.get('.private_segment_fixed_size'), 'lds_bytes': k.get('.group_segment_fixed_size'),
                          'dynamic_stack': bool(k.get('.uses_dynamic_stack', False)),
                          'max_threads': k.get('.max_flat_workgroup_size')}
     with open(cache, 'w') as fh:

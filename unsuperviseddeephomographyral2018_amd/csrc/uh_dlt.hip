@@ -6,6 +6,8 @@
 // row broadcasts done by v_readlane / ds_bpermute instead of memory.  No LDS, no barriers; 4 systems
 // per 256-thread block.  Latency-bound by construction (0.4 kB per pair): the point is one launch
 // instead of ~40 TF ops, and bit-reproducible results.
+#include <mutex>
+
 #include "uh_device.h"
 #include "uh_host.h"
 
@@ -233,10 +235,19 @@ extern "C" int uh_dlt_zeroed_pairs(unsigned long long* count, int reset, uh_stre
     // enqueued on `stream` takes (and clears) the counter, an async copy brings it to the host, the stream is waited for.
     // Pairs zeroed by launches on OTHER streams that have not executed yet are counted by the next call: nothing is lost,
     // nothing is counted twice.  A capturing stream is refused (a synchronising call would invalidate the capture).
+    // The take lands in ONE device word (g_dlt_zeroed_taken) before it is copied out: two host threads on two streams could
+    // otherwise interleave take A, take B, copy A, copy B and lose A's count -> the take / copy / wait sequence is serialised.
     if (!count) return UH_E_NULL;
     hipStream_t s = (hipStream_t)stream;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return UH_E_CAPTURING;
+    // (the NULL stream cannot be captured itself, but it may not be synchronised while a blocking capture is open elsewhere:
+    //  HIP reports that as hipErrorStreamCaptureImplicit)
+    const hipError_t q = hipStreamIsCapturing(s, &cs);
+    if (q == hipErrorStreamCaptureImplicit) { (void)hipGetLastError(); return UH_E_CAPTURING; }
+    if (q != hipSuccess) return (int)q;
+    if (cs != hipStreamCaptureStatusNone) return UH_E_CAPTURING;
+    static std::mutex take_mutex;
+    std::lock_guard<std::mutex> lock(take_mutex);
     hipLaunchKernelGGL(uh::dlt_take_zeroed_kernel, dim3(1), dim3(1), 0, s, reset ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -1,57 +1,30 @@
-// uh_epilogue.hip -- bias + ReLU epilogue of the regressor's conv layers, forward and backward (gfx950).
+// uh_epilogue.hip -- bias + ReLU (+ 2x2/2 max-pool) epilogue of the regressor's conv layers, forward and backward (gfx950).
 //
 // NOT part of the reference's hot path: the conv GEMMs stay stock MIOpen (north_star).  In eager PyTorch every
 // `_conv2d` of /root/reference/code/homography_model.py:88-95 (conv + bias + ReLU) costs three extra full passes over
 // the activation per step: bias add and ReLU in the forward, and in the backward a ReLU-mask pass plus a separate
-// per-channel reduction for the bias gradient -- ~1.1 ms of a 6.8 ms step at batch 64.  These two kernels do
-//   forward : y <- max(y + b[c], 0)                       in place, one pass
-//   backward: g = (y > 0) ? gy : 0,  db[c] = sum g        one pass + a tiny deterministic finishing reduction
-// on the NHWC (channels_last) activation, 16 bytes per lane.  HBM-bound: 8 / 12 bytes per element.
+// per-channel reduction for the bias gradient -- ~1.1 ms of a 6.8 ms step at batch 64.  These kernels do
+//   forward : y <- max(y + b[c], 0) in place + ONE BIT per element (y > 0) for the backward      8.03 B/element
+//   backward: g = bit ? gy : 0,  db[c] = sum g   (+ a tiny deterministic finishing reduction)     8.03 B/element
+// on the NHWC (channels_last) activation, 16 bytes per lane per access.  HBM-bound.
+//
+// What the backward needs is kept as BITS, not as the activation (round 6; rounds 1-5 re-read y: 12 B/element in the backward,
+// and the pooled variant wrote relu(y + b) back at full resolution in the forward only to read it again: 9 + 9 B per conv-output
+// element).  bias+ReLU needs one bit per element; bias+ReLU+pool needs, per pooled element, which of its four window elements
+// received the gradient (none when the maximum is not positive) -- nothing downstream reads the full-resolution relu(y + b): the
+// next conv consumes `pooled`.  Measured on the batch-64 step: the four kernels 568 -> 428 us, +2.7 % pairs/s
+// (profiles/r06_epi_ab.jsonl, three alternating pairs in one session).
+// Mask layout (opaque to the caller; produced by the forward, consumed by the backward of the same shape):
+//   bias+ReLU       the float4 stream is cut into chunks of 128; lane l of the wave that owns chunk c holds float4 128c + l and
+//                   128c + 64 + l and stores ONE byte mask[64c + l] = bits(first) | bits(second) << 4 (64 B per wave, coalesced)
+//   pool            one uint16 per (pooled pixel, channel quad): bit 4k + j = "window element k of component j gets the gradient"
+//                   (k = 0..3: (2i,2j) (2i,2j+1) (2i+1,2j) (2i+1,2j+1); first maximum wins a tie, as max_pool2d; live = max > 0)
 #include "uh_device.h"
 #include "uh_host.h"
 
 namespace uh {
 
 constexpr int EPI_BLOCKS = 1024;     // upper bound of the grid; every thread keeps ONE channel quad (1024 % C == 0)
-
-__global__ __launch_bounds__(256) void bias_relu_forward_kernel(float4* __restrict__ y, const float* __restrict__ bias,
-                                                                size_t n4, int C) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const float4 b = *reinterpret_cast<const float4*>(bias + (int)((t * 4) % (size_t)C));
-    const size_t stride = (size_t)gridDim.x * 256;      // stride*4 is a multiple of C: the channel quad never changes
-    for (size_t i = t; i < n4; i += stride) {
-        float4 v = y[i];
-        v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
-        v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
-        y[i] = v;
-    }
-}
-
-__global__ __launch_bounds__(256) void bias_relu_backward_kernel(const float4* __restrict__ y, const float4* __restrict__ gy,
-                                                                 float4* __restrict__ g, float* __restrict__ partial,
-                                                                 size_t n4, int C) {
-    __shared__ float4 sm[256];
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * 256;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = t; i < n4; i += stride) {
-        const float4 a = y[i];
-        float4 d = gy[i];
-        d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f;
-        d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
-        g[i] = d;
-        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
-    }
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    // threads tid, tid + C/4, tid + 2C/4 ... hold the same channel quad
-    const int q = C / 4;
-    if ((int)threadIdx.x < q) {
-        float4 s = sm[threadIdx.x];
-        for (int k = threadIdx.x + q; k < 256; k += q) { const float4 v = sm[k]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * C + threadIdx.x * 4) = s;
-    }
-}
 
 // db[c] = sum over blocks of partial[blk][c] in fixed order.  One block of 1024 threads: thread = (row r, channel c),
 // R = 1024 / C rows walk the partial blocks with stride R (coalesced: a wave reads 64 consecutive channels), the R row
@@ -85,87 +58,9 @@ __global__ __launch_bounds__(1024) void bias_grad_finish_kernel(const float* __r
     }
 }
 
-// ---- the same epilogue fused with the 2x2/2 max-pool that follows the second conv of a block (_maxpool2d, :102-105) ----
-// forward : y <- max(y + b, 0) in place (kept for the backward), p[n, i, j, c] = max of the 2x2 window of y
-// backward: g = gp[n, i/2, j/2, c] where y is the (first) maximum of its window and y > 0, else 0; db[c] = sum g.
-// A window whose four values tie (typically all 0 after the ReLU) routes the gradient to its first element, as
-// max_pool2d does -- where the ReLU mask then zeroes it anyway.  One thread = one pooled pixel x one channel quad.
 __device__ __forceinline__ float4 relu_bias4(float4 v, float4 b) {
     return make_float4(fmaxf(v.x + b.x, 0.f), fmaxf(v.y + b.y, 0.f), fmaxf(v.z + b.z, 0.f), fmaxf(v.w + b.w, 0.f));
 }
-__device__ __forceinline__ float4 max4(float4 a, float4 b) {
-    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
-}
-
-__global__ __launch_bounds__(256) void bias_relu_pool_forward_kernel(float4* __restrict__ y, const float* __restrict__ bias,
-                                                                     float4* __restrict__ p, size_t nq, int Hp, int Wp,
-                                                                     int q /* = C/4 */) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const float4 b = *reinterpret_cast<const float4*>(bias + (int)(t % (size_t)q) * 4);
-    const size_t stride = (size_t)gridDim.x * 256;          // multiple of q: the channel quad never changes
-    const size_t rowq = (size_t)2 * Wp * q;                  // float4s per input row
-    for (size_t i = t; i < nq; i += stride) {
-        const size_t pix = i / q; const int cq = (int)(i - pix * q);
-        const size_t n_i = pix / Wp; const int j = (int)(pix - n_i * Wp);      // n_i = n*Hp + i
-        const size_t base = (n_i * 2) * rowq + (size_t)(2 * j) * q + cq;       // (n, 2i, 2j, cq)
-        const float4 a0 = relu_bias4(y[base], b), a1 = relu_bias4(y[base + q], b);
-        const float4 a2 = relu_bias4(y[base + rowq], b), a3 = relu_bias4(y[base + rowq + q], b);
-        y[base] = a0; y[base + q] = a1; y[base + rowq] = a2; y[base + rowq + q] = a3;
-        p[i] = max4(max4(a0, a1), max4(a2, a3));
-    }
-}
-
-__device__ __forceinline__ void route(float y0, float y1, float y2, float y3, float gp, float& g0, float& g1, float& g2, float& g3) {
-    const float m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
-    const float live = m > 0.f ? gp : 0.f;                   // ReLU mask of the selected element
-    const bool s0 = y0 == m, s1 = !s0 && y1 == m, s2 = !s0 && !s1 && y2 == m, s3 = !s0 && !s1 && !s2;
-    g0 = s0 ? live : 0.f; g1 = s1 ? live : 0.f; g2 = s2 ? live : 0.f; g3 = s3 ? live : 0.f;
-}
-
-__global__ __launch_bounds__(256) void bias_relu_pool_backward_kernel(const float4* __restrict__ y, const float4* __restrict__ gp,
-                                                                      float4* __restrict__ g, float* __restrict__ partial,
-                                                                      size_t nq, int Hp, int Wp, int q) {
-    __shared__ float4 sm[256];
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * 256;
-    const size_t rowq = (size_t)2 * Wp * q;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = t; i < nq; i += stride) {
-        const size_t pix = i / q; const int cq = (int)(i - pix * q);
-        const size_t n_i = pix / Wp; const int j = (int)(pix - n_i * Wp);
-        const size_t base = (n_i * 2) * rowq + (size_t)(2 * j) * q + cq;
-        const float4 a0 = y[base], a1 = y[base + q], a2 = y[base + rowq], a3 = y[base + rowq + q];
-        const float4 d = gp[i];
-        float4 g0, g1, g2, g3;
-        route(a0.x, a1.x, a2.x, a3.x, d.x, g0.x, g1.x, g2.x, g3.x);
-        route(a0.y, a1.y, a2.y, a3.y, d.y, g0.y, g1.y, g2.y, g3.y);
-        route(a0.z, a1.z, a2.z, a3.z, d.z, g0.z, g1.z, g2.z, g3.z);
-        route(a0.w, a1.w, a2.w, a3.w, d.w, g0.w, g1.w, g2.w, g3.w);
-        g[base] = g0; g[base + q] = g1; g[base + rowq] = g2; g[base + rowq + q] = g3;
-        acc.x += (g0.x + g1.x) + (g2.x + g3.x); acc.y += (g0.y + g1.y) + (g2.y + g3.y);
-        acc.z += (g0.z + g1.z) + (g2.z + g3.z); acc.w += (g0.w + g1.w) + (g2.w + g3.w);
-    }
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    if ((int)threadIdx.x < q) {
-        float4 s = sm[threadIdx.x];
-        for (int k = threadIdx.x + q; k < 256; k += q) { const float4 v = sm[k]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * q * 4 + threadIdx.x * 4) = s;
-    }
-}
-
-// ---- the same two epilogues with the backward's knowledge kept as BITS instead of as the activation itself --------------
-// The backward of bias+ReLU needs one bit per element (y > 0); the backward of bias+ReLU+pool needs, per pooled element, which
-// of its four window elements received the gradient (none when the maximum is not positive).  Reading y back for that costs
-// 4 B/element in the backward, and the pooled variant must also WRITE relu(y + b) back at full resolution in the forward
-// although nothing downstream reads it (the next conv consumes `pooled`).  With the bits kept instead (1 bit per element):
-//   bias+ReLU       forward 8 -> 8.03 B/elem, backward 12 -> 8.03 B/elem
-//   bias+ReLU+pool  forward 9 -> 5.03 B/elem (of y), backward 9 -> 5.03 B/elem
-// Layout (opaque to the caller; produced by the forward, consumed by the backward):
-//   bias+ReLU       the float4 stream is cut into chunks of 128; lane l of the wave that owns chunk c holds float4 128c + l and
-//                   128c + 64 + l and stores ONE byte mask[64c + l] = bits(first) | bits(second) << 4 (64 B per wave, coalesced)
-//   pool            one uint16 per (pooled pixel, channel quad): bit 4k + j = "window element k of component j gets the gradient"
-//                   (k = 0..3: (2i,2j) (2i,2j+1) (2i+1,2j) (2i+1,2j+1); first maximum wins a tie, as max_pool2d; live = max > 0)
 __device__ __forceinline__ unsigned pos4(float4 v) {
     return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
 }
@@ -173,7 +68,7 @@ __device__ __forceinline__ float4 keep4(float4 d, unsigned bits) {
     return make_float4((bits & 1u) ? d.x : 0.f, (bits & 2u) ? d.y : 0.f, (bits & 4u) ? d.z : 0.f, (bits & 8u) ? d.w : 0.f);
 }
 
-__global__ __launch_bounds__(256) void bias_relu_forward_bits_kernel(float4* __restrict__ y, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void bias_relu_forward_kernel(float4* __restrict__ y, const float* __restrict__ bias,
                                                                      unsigned char* __restrict__ mask, size_t n4, int q /* = C/4 */) {
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (size_t)gridDim.x * 4;
@@ -188,12 +83,12 @@ __global__ __launch_bounds__(256) void bias_relu_forward_bits_kernel(float4* __r
         if (ok0) v0 = y[i0];
         if (ok1) v1 = y[i1];
         v0 = relu_bias4(v0, b0); v1 = relu_bias4(v1, b1);
-        if (ok0) { y[i0] = v0; mask[c * 64 + lane] = (unsigned char)(pos4(v0) | (ok1 ? pos4(v1) << 4 : 0u)); }
+        if (ok0) { y[i0] = v0; if (mask) mask[c * 64 + lane] = (unsigned char)(pos4(v0) | (ok1 ? pos4(v1) << 4 : 0u)); }
         if (ok1) y[i1] = v1;
     }
 }
 
-__global__ __launch_bounds__(256) void bias_relu_backward_bits_kernel(const unsigned char* __restrict__ mask,
+__global__ __launch_bounds__(256) void bias_relu_backward_kernel(const unsigned char* __restrict__ mask,
                                                                       const float4* __restrict__ gy, float4* __restrict__ g,
                                                                       float* __restrict__ partial, size_t n4, int q) {
     __shared__ float4 sm[512];
@@ -232,7 +127,7 @@ __device__ __forceinline__ unsigned route_bits(float y0, float y1, float y2, flo
     return m > 0.f ? sel : 0u;
 }
 
-__global__ __launch_bounds__(256) void bias_relu_pool_forward_bits_kernel(const float4* __restrict__ y, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void bias_relu_pool_forward_kernel(const float4* __restrict__ y, const float* __restrict__ bias,
                                                                           float4* __restrict__ p, unsigned short* __restrict__ mask,
                                                                           size_t nq, int Hp, int Wp, int q) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -253,7 +148,7 @@ __global__ __launch_bounds__(256) void bias_relu_pool_forward_bits_kernel(const 
     }
 }
 
-__global__ __launch_bounds__(256) void bias_relu_pool_backward_bits_kernel(const unsigned short* __restrict__ mask,
+__global__ __launch_bounds__(256) void bias_relu_pool_backward_kernel(const unsigned short* __restrict__ mask,
                                                                            const float4* __restrict__ gp, float4* __restrict__ g,
                                                                            float* __restrict__ partial, size_t nq, int Hp, int Wp,
                                                                            int q) {
@@ -289,8 +184,9 @@ static unsigned epi_grid2(size_t n4) {
     return (unsigned)(g < 1 ? 1 : (g > (size_t)EPI_BLOCKS ? (size_t)EPI_BLOCKS : g));
 }
 
-static unsigned epi_grid(size_t n4) {
-    const size_t g = (n4 + 255) / 256;
+// grid of the pooled kernels: one thread per (pooled pixel, channel quad)
+static unsigned epi_grid(size_t nq) {
+    const size_t g = (nq + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > (size_t)EPI_BLOCKS ? (size_t)EPI_BLOCKS : g));
 }
 
@@ -304,30 +200,35 @@ static int check_epi(size_t npix, int C) {
     return 0;
 }
 
-extern "C" int uh_bias_relu_forward(float* y, const float* bias, size_t npix, int C, uh_stream_t stream) {
-    if (!y || !bias) return UH_E_NULL;
+extern "C" size_t uh_relu_mask_bytes(size_t npix, int C) {
+    if (check_epi(npix, C)) return 0;
+    return ((npix * (size_t)C / 4 + 127) / 128) * 64;
+}
+
+extern "C" int uh_bias_relu_forward(float* y, const float* bias, void* mask, size_t npix, int C, uh_stream_t stream) {
+    if (!y || !bias) return UH_E_NULL;                            // mask may be NULL: forward only (no backward will follow)
     if (int e = check_epi(npix, C)) return e;
     const size_t n4 = npix * (size_t)C / 4;
-    launch_timed(UH_K_EPI_FWD, bias_relu_forward_kernel, dim3(epi_grid(n4)), dim3(256), (hipStream_t)stream,
-                 reinterpret_cast<float4*>(y), bias, n4, C);
+    launch_timed(UH_K_EPI_FWD, bias_relu_forward_kernel, dim3(epi_grid2(n4)), dim3(256), (hipStream_t)stream,
+                 reinterpret_cast<float4*>(y), bias, (unsigned char*)mask, n4, C / 4);
     return (int)hipGetLastError();
 }
 
 extern "C" size_t uh_bias_relu_backward_workspace_bytes(size_t npix, int C) {
     if (check_epi(npix, C)) return 0;
-    return (size_t)epi_grid(npix * (size_t)C / 4) * C * sizeof(float);
+    return (size_t)epi_grid2(npix * (size_t)C / 4) * C * sizeof(float);
 }
 
-extern "C" int uh_bias_relu_backward(const float* y, const float* gy, float* g, float* dbias, void* workspace,
+extern "C" int uh_bias_relu_backward(const void* mask, const float* gy, float* g, float* dbias, void* workspace,
                                      size_t workspace_bytes, size_t npix, int C, uh_stream_t stream) {
-    if (!y || !gy || !g || !dbias) return UH_E_NULL;
+    if (!mask || !gy || !g || !dbias) return UH_E_NULL;
     if (int e = check_epi(npix, C)) return e;
     if (!workspace || workspace_bytes < uh_bias_relu_backward_workspace_bytes(npix, C)) return UH_E_WORKSPACE;
     const size_t n4 = npix * (size_t)C / 4;
-    const unsigned grid = epi_grid(n4);
+    const unsigned grid = epi_grid2(n4);
     hipStream_t s = (hipStream_t)stream;
-    launch_timed(UH_K_EPI_BWD, bias_relu_backward_kernel, dim3(grid), dim3(256), s, reinterpret_cast<const float4*>(y),
-                 reinterpret_cast<const float4*>(gy), reinterpret_cast<float4*>(g), (float*)workspace, n4, C);
+    launch_timed(UH_K_EPI_BWD, bias_relu_backward_kernel, dim3(grid), dim3(256), s, (const unsigned char*)mask,
+                 reinterpret_cast<const float4*>(gy), reinterpret_cast<float4*>(g), (float*)workspace, n4, C / 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
@@ -335,20 +236,26 @@ extern "C" int uh_bias_relu_backward(const float* y, const float* gy, float* g, 
 }
 
 // ---- with the 2x2/2 max-pool ---------------------------------------------------------------------------
-// y [N,H,W,C] (H, W even), p / gp [N,H/2,W/2,C].  npool = N * (H/2) * (W/2).
+// y [N,H,W,C] (H, W even), p / gp [N,H/2,W/2,C].
 static int check_pool(int N, int H, int W, int C) {
     if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return UH_E_SHAPE;
     return check_epi((size_t)N * H * W, C);
 }
 
-extern "C" int uh_bias_relu_pool_forward(float* y, const float* bias, float* pooled, int N, int H, int W, int C,
-                                         uh_stream_t stream) {
-    if (!y || !bias || !pooled) return UH_E_NULL;
+extern "C" size_t uh_pool_mask_bytes(int N, int H, int W, int C) {
+    if (check_pool(N, H, W, C)) return 0;
+    return (size_t)N * (H / 2) * (W / 2) * (C / 4) * sizeof(unsigned short);
+}
+
+extern "C" int uh_bias_relu_pool_forward(const float* y, const float* bias, float* pooled, void* mask, int N, int H, int W,
+                                         int C, uh_stream_t stream) {
+    if (!y || !bias || !pooled) return UH_E_NULL;                 // mask may be NULL: forward only
     if (int e = check_pool(N, H, W, C)) return e;
     const int q = C / 4;
     const size_t nq = (size_t)N * (H / 2) * (W / 2) * q;
     launch_timed(UH_K_EPI_FWD, bias_relu_pool_forward_kernel, dim3(epi_grid(nq)), dim3(256), (hipStream_t)stream,
-                 reinterpret_cast<float4*>(y), bias, reinterpret_cast<float4*>(pooled), nq, H / 2, W / 2, q);
+                 reinterpret_cast<const float4*>(y), bias, reinterpret_cast<float4*>(pooled), (unsigned short*)mask, nq, H / 2,
+                 W / 2, q);
     return (int)hipGetLastError();
 }
 
@@ -357,79 +264,8 @@ extern "C" size_t uh_bias_relu_pool_backward_workspace_bytes(int N, int H, int W
     return (size_t)epi_grid((size_t)N * (H / 2) * (W / 2) * (C / 4)) * C * sizeof(float);
 }
 
-extern "C" int uh_bias_relu_pool_backward(const float* y, const float* gpooled, float* g, float* dbias, void* workspace,
+extern "C" int uh_bias_relu_pool_backward(const void* mask, const float* gpooled, float* g, float* dbias, void* workspace,
                                           size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream) {
-    if (!y || !gpooled || !g || !dbias) return UH_E_NULL;
-    if (int e = check_pool(N, H, W, C)) return e;
-    if (!workspace || workspace_bytes < uh_bias_relu_pool_backward_workspace_bytes(N, H, W, C)) return UH_E_WORKSPACE;
-    const int q = C / 4;
-    const size_t nq = (size_t)N * (H / 2) * (W / 2) * q;
-    const unsigned grid = epi_grid(nq);
-    hipStream_t s = (hipStream_t)stream;
-    launch_timed(UH_K_EPI_BWD, bias_relu_pool_backward_kernel, dim3(grid), dim3(256), s, reinterpret_cast<const float4*>(y),
-                 reinterpret_cast<const float4*>(gpooled), reinterpret_cast<float4*>(g), (float*)workspace, nq, H / 2, W / 2, q);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
-    return (int)hipGetLastError();
-}
-
-
-// ---- bit-mask variants (see the kernels): the backward reads gy + 1 bit per element instead of gy + y --------------------
-extern "C" size_t uh_relu_mask_bytes(size_t npix, int C) {
-    if (check_epi(npix, C)) return 0;
-    return ((npix * (size_t)C / 4 + 127) / 128) * 64;
-}
-
-extern "C" int uh_bias_relu_forward_bits(float* y, const float* bias, void* mask, size_t npix, int C, uh_stream_t stream) {
-    if (!y || !bias || !mask) return UH_E_NULL;
-    if (int e = check_epi(npix, C)) return e;
-    const size_t n4 = npix * (size_t)C / 4;
-    launch_timed(UH_K_EPI_FWD, bias_relu_forward_bits_kernel, dim3(epi_grid2(n4)), dim3(256), (hipStream_t)stream,
-                 reinterpret_cast<float4*>(y), bias, (unsigned char*)mask, n4, C / 4);
-    return (int)hipGetLastError();
-}
-
-extern "C" size_t uh_bias_relu_backward_bits_workspace_bytes(size_t npix, int C) {
-    if (check_epi(npix, C)) return 0;
-    return (size_t)epi_grid2(npix * (size_t)C / 4) * C * sizeof(float);
-}
-
-extern "C" int uh_bias_relu_backward_bits(const void* mask, const float* gy, float* g, float* dbias, void* workspace,
-                                          size_t workspace_bytes, size_t npix, int C, uh_stream_t stream) {
-    if (!mask || !gy || !g || !dbias) return UH_E_NULL;
-    if (int e = check_epi(npix, C)) return e;
-    if (!workspace || workspace_bytes < uh_bias_relu_backward_bits_workspace_bytes(npix, C)) return UH_E_WORKSPACE;
-    const size_t n4 = npix * (size_t)C / 4;
-    const unsigned grid = epi_grid2(n4);
-    hipStream_t s = (hipStream_t)stream;
-    launch_timed(UH_K_EPI_BWD, bias_relu_backward_bits_kernel, dim3(grid), dim3(256), s, (const unsigned char*)mask,
-                 reinterpret_cast<const float4*>(gy), reinterpret_cast<float4*>(g), (float*)workspace, n4, C / 4);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
-    return (int)hipGetLastError();
-}
-
-extern "C" size_t uh_pool_mask_bytes(int N, int H, int W, int C) {
-    if (check_pool(N, H, W, C)) return 0;
-    return (size_t)N * (H / 2) * (W / 2) * (C / 4) * sizeof(unsigned short);
-}
-
-extern "C" int uh_bias_relu_pool_forward_bits(const float* y, const float* bias, float* pooled, void* mask, int N, int H, int W,
-                                              int C, uh_stream_t stream) {
-    if (!y || !bias || !pooled) return UH_E_NULL;                 // mask may be NULL: forward only (no backward will follow)
-    if (int e = check_pool(N, H, W, C)) return e;
-    const int q = C / 4;
-    const size_t nq = (size_t)N * (H / 2) * (W / 2) * q;
-    launch_timed(UH_K_EPI_FWD, bias_relu_pool_forward_bits_kernel, dim3(epi_grid(nq)), dim3(256), (hipStream_t)stream,
-                 reinterpret_cast<const float4*>(y), bias, reinterpret_cast<float4*>(pooled), (unsigned short*)mask, nq, H / 2,
-                 W / 2, q);
-    return (int)hipGetLastError();
-}
-
-extern "C" int uh_bias_relu_pool_backward_bits(const void* mask, const float* gpooled, float* g, float* dbias, void* workspace,
-                                               size_t workspace_bytes, int N, int H, int W, int C, uh_stream_t stream) {
     if (!mask || !gpooled || !g || !dbias) return UH_E_NULL;
     if (int e = check_pool(N, H, W, C)) return e;
     if (!workspace || workspace_bytes < uh_bias_relu_pool_backward_workspace_bytes(N, H, W, C)) return UH_E_WORKSPACE;
@@ -437,7 +273,7 @@ extern "C" int uh_bias_relu_pool_backward_bits(const void* mask, const float* gp
     const size_t nq = (size_t)N * (H / 2) * (W / 2) * q;
     const unsigned grid = epi_grid(nq);
     hipStream_t s = (hipStream_t)stream;
-    launch_timed(UH_K_EPI_BWD, bias_relu_pool_backward_bits_kernel, dim3(grid), dim3(256), s, (const unsigned short*)mask,
+    launch_timed(UH_K_EPI_BWD, bias_relu_pool_backward_kernel, dim3(grid), dim3(256), s, (const unsigned short*)mask,
                  reinterpret_cast<const float4*>(gpooled), reinterpret_cast<float4*>(g), (float*)workspace, nq, H / 2, W / 2, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -144,6 +144,7 @@ def tune_gemms(max_ms_per_solution=15, max_iterations=20, filename=None):
             except OSError:
                 d = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'uh_hotpath_uid%d' % os.getuid())
                 os.makedirs(d, mode=0o700, exist_ok=True)
+            d = _private_dir_or_fresh(d)
             filename = os.path.join(d, 'tunableop%s.csv' % ('_r' + lr + '_' if lr is not None else ''))
         tun.set_filename(filename, insert_device_ordinal=True)
         tun.set_max_tuning_duration(int(max_ms_per_solution))
@@ -153,6 +154,21 @@ def tune_gemms(max_ms_per_solution=15, max_iterations=20, filename=None):
         return True
     except Exception:                                        # noqa: BLE001 -- an optimisation, never a requirement
         return False
+
+
+def _private_dir_or_fresh(d):
+    """`d` if it is a real directory owned by this user that nobody else can write to; otherwise a fresh mkdtemp directory (no
+    caching across processes, but never a results file another user could have planted: makedirs(exist_ok=True) accepts a
+    directory somebody else created first in a world-writable $TMPDIR)."""
+    import stat
+    import tempfile
+    try:
+        st = os.lstat(d)
+        if stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o022) == 0:
+            return d
+    except OSError:
+        pass
+    return tempfile.mkdtemp(prefix='uh_hotpath_')
 
 
 def seed_tower_rng(seed, rank):
@@ -279,17 +295,22 @@ class GradAverager(object):
 XGMI_LINK_GBS = 153.0        # per direction per link, 7 links per GPU on an 8-GPU MI355X node
 
 
-def exchange_report(averager, run_steps, ms_per_step, steps_without=10, bucket_iters=5):
+def exchange_report(averager, run_steps, ms_per_step=None, steps_without=10, bucket_iters=5, resync=None):
     """What the gradient exchange costs, readable from ONE line of the first real multi-GPU run.  Collective:
     every rank must call it, after the timed region.
       buckets                    stand-alone all-reduce time per bucket (nothing to hide under), algbw / busbw, and busbw as a
                                  fraction of the xGMI bandwidth a rank can use towards its world - 1 peers (links x 153 GB/s)
       ms_per_step_no_exchange    `steps_without` more steps with the averager DISABLED on every rank (each tower keeps its own
                                  gradient; barrier + device sync either side, MAX over ranks) -- the step without the exchange
+      ms_per_step_with_exchange  only when ms_per_step is None: `steps_without` steps with the exchange ON, timed the same way
       exchange_cost_ms_per_step  ms_per_step - ms_per_step_no_exchange: the un-hidden part of the exchange PLUS what the RCCL
                                  kernels take from the conv backward they overlap (CU / HBM contention) -- the number
                                  host_blocked_ms_per_step cannot show on RCCL, whose wait() only enqueues a stream dependency
-    run_steps(n) runs n training steps of the caller's TrainStep."""
+    run_steps(n) runs n training steps of the caller's TrainStep.
+    The no-exchange steps are REAL steps (optimizer included) on per-tower gradients, so the replicas diverge: pass
+    resync=(module, optimizer) and rank 0's variables, buffers and optimizer state are broadcast afterwards (broadcast_state) --
+    ranks leave the call in step.  Without it the call is destructive and belongs at the very end of a run.  An exception on
+    ONE rank inside a collective leaves the others waiting: call it where a hang costs nothing but the diagnostic."""
     import time
     world = averager.world
     out = {'reduce_op': 'AVG' if averager._avg_in_collective else 'SUM+div',
@@ -307,16 +328,23 @@ def exchange_report(averager, run_steps, ms_per_step, steps_without=10, bucket_i
         out['buckets'] = {'error': '%s: %s' % (type(e).__name__, e)}
     dev = averager.buckets[0]['flat'].device if averager.buckets else torch.device('cpu')
     sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == 'cuda' else (lambda: None)
-    try:
-        averager.enabled = False
-        run_steps(2)                                        # settle (the allocator sees a step without the collectives)
+
+    def timed(n):                                           # barrier + device sync either side, MAX over ranks -> ms per step
         sync(); dist.barrier(); sync()
         t0 = time.perf_counter()
-        run_steps(steps_without)
+        run_steps(n)
         sync(); dist.barrier(); sync()
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms_wo = float(tt.item()) / steps_without * 1e3
+        return float(tt.item()) / n * 1e3
+    try:
+        if ms_per_step is None:                             # the caller has no like-for-like figure (a trainer whose loop also
+            run_steps(2)                                    # draws inputs and logs): time the step WITH the exchange the same way
+            ms_per_step = timed(steps_without)
+            out['ms_per_step_with_exchange'] = round(ms_per_step, 3)
+        averager.enabled = False
+        run_steps(2)                                        # settle (the allocator sees a step without the collectives)
+        ms_wo = timed(steps_without)
         out['ms_per_step_no_exchange'] = round(ms_wo, 3)
         out['exchange_cost_ms_per_step'] = round(ms_per_step - ms_wo, 3)
         out['steps_without_exchange'] = steps_without
@@ -324,10 +352,42 @@ def exchange_report(averager, run_steps, ms_per_step, steps_without=10, bucket_i
         out['ms_per_step_no_exchange'] = {'error': '%s: %s' % (type(e).__name__, e)}
     finally:
         averager.enabled = True
+        # the steps above applied each tower's OWN gradient: variables (and optimizer moments) have diverged across ranks.
+        # Put every rank back on rank 0's state so that a caller that goes on training keeps identical replicas.
+        if resync is not None:
+            try:
+                out['resynced_tensors'] = broadcast_state(resync)
+            except Exception as e:                              # noqa: BLE001
+                out['resynced_tensors'] = {'error': '%s: %s' % (type(e).__name__, e)}
     out['note'] = ('bucket 0 = fc2+fc1 (issued first in backward, overlaps the conv backward), bucket 1 = conv; RCCL wait() only '
                    'enqueues a stream dependency, so host_blocked is ~0 by construction: exchange_cost_ms_per_step is the figure '
                    'that shows what the exchange really costs (un-hidden time + contention with the conv backward)')
     return out
+
+
+def broadcast_state(module_and_optimizer, src=0):
+    """Broadcast rank `src`'s variables, buffers and optimizer state tensors (Adam moments, step counts) to every rank, in a
+    fixed order.  -> number of tensors sent.  Collective."""
+    module, opt = module_and_optimizer
+    n = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+        n += 1
+    if opt is not None:
+        for group in opt.param_groups:
+            for p in group['params']:
+                st = opt.state.get(p, {})
+                for k in sorted(st):
+                    v = st[k]
+                    if torch.is_tensor(v):
+                        if v.device.type == 'cpu' and dist.get_backend() == 'nccl':      # a host-side step counter: via the device
+                            tmp = v.to(p.device)
+                            dist.broadcast(tmp, src=src)
+                            v.copy_(tmp.cpu())
+                        else:
+                            dist.broadcast(v, src=src)
+                        n += 1
+    return n
 
 
 def all_reduce_mean_scalars(values, world):

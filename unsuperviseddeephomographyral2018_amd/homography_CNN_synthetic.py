@@ -107,6 +107,12 @@ def build_parser():
     p.add_argument('--decode_workers', type=int, default=-1,
                    help='--data_path: image-decode worker PROCESSES (dataloader.Dataloader(num_workers=...)); 0 = the 20-thread '
                         'pool (interpreter-lock bound at ~2 000 pairs/s); -1 = min(16, host cores / (4 x ranks)) per rank')
+    p.add_argument('--exchange_report', type=str2bool, default='True',
+                   help='world > 1: after training, print what the gradient exchange cost (dist.exchange_report; ~25 extra steps, '
+                        'the trained state is restored afterwards)')
+    p.add_argument('--test_shuffle', type=str2bool, default='False',
+                   help='test mode with --data_path: True = shuffle the test list as the reference does (Dataloader(..., shuffle=True), '
+                        ':404); default: walk it in order -- every pair exactly 3 times, reproducible statistics')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--log_every', type=int, default=100)
     p.add_argument('--save_every', type=int, default=1000)
@@ -408,33 +414,37 @@ def train(args):
                 batch = synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
                                              seed=args.seed + step * world + rank, device=device, kind=args.texture)
             model = step_fn(batch)
-            vals = uh_dist.all_reduce_mean_scalars([getattr(model, n) for n in names], world)
-            cur = torch.stack([v.detach() for v in vals])
+            # Monitors (:333-352): each rank keeps running sums of ITS tower's six loss values on its device -- no collective and no
+            # host sync in the hot loop.  They meet at LOG steps only (total_*_loss = reduce_mean over towers, :279-284; SURVEY
+            # 8e "loss scalars all-reduced only for logging"): one all-reduce of 14 floats + the zeroed-pair count every
+            # --log_every steps.  Means are linear, so the printed figures equal a per-step mean over towers.
+            cur = torch.stack([getattr(model, n).detach().float().reshape(()) for n in names])
             finite = torch.isfinite(cur)
             nonfinite_steps += (~finite.all()).float()          # a degenerate pair makes that step's loss VALUE NaN (its gradient is
             cur = torch.where(finite, cur, torch.zeros_like(cur))   # zeroed in the DLT backward): keep it out of the running means
             totals += cur
             window += cur
             win_n += 1
-            if step % args.log_every == 0:                       # every rank: its device's count of zeroed pairs, summed over ranks
+            if step % args.log_every == 0:
                 z = _lib.dlt_zeroed_pairs(reset=True)            # (synchronous read of a device counter: log time only)
-                if world > 1:
-                    zt = torch.tensor([z], dtype=torch.int64, device=device)
-                    torch.distributed.all_reduce(zt)
-                    z = int(zt.item())
-                zeroed_pairs += z
-            if rank == 0 and step % args.log_every == 0:
-                n = step - start_step + 1
-                avg = (totals / n).tolist()                      # running means since the start, as the reference prints (:345-352)
-                win = (window / win_n).tolist()                  # ... and the mean over the steps since the previous log line
-                dt = time.time() - t0
-                print('Train: step %d  ' % step + ', '.join('%s %.6f' % (k, v) for k, v in zip(names, avg))
-                      + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
-                      + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)])
-                      + ('  | %d steps with a non-finite loss value so far' % int(nonfinite_steps) if float(nonfinite_steps) else '')
-                      + ('  | %d pairs had a non-finite gradient zeroed so far (--zero_nonfinite_grad; the reference would have '
-                         'propagated NaN)' % zeroed_pairs if zeroed_pairs else ''),
-                      flush=True)
+                mon = torch.cat([totals, window, nonfinite_steps.reshape(1), torch.tensor([float(z)], device=device)]).double()
+                if world > 1:                                    # the ONE logging collective: sums over ranks
+                    torch.distributed.all_reduce(mon)
+                k = len(names)
+                zeroed_pairs += int(round(float(mon[2 * k + 1])))
+                if rank == 0:
+                    n = step - start_step + 1
+                    avg = (mon[:k] / (world * n)).tolist()           # running means since the start, as the reference prints (:345-352)
+                    win = (mon[k:2 * k] / (world * win_n)).tolist()  # ... and the mean over the steps since the previous log line
+                    nf = int(round(float(mon[2 * k])))
+                    dt = time.time() - t0
+                    print('Train: step %d  ' % step + ', '.join('%s %.6f' % (kk, v) for kk, v in zip(names, avg))
+                          + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
+                          + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)])
+                          + ('  | %d tower-steps with a non-finite loss value so far' % nf if nf else '')
+                          + ('  | %d pairs had a non-finite gradient zeroed so far (--zero_nonfinite_grad; the reference would have '
+                             'propagated NaN)' % zeroed_pairs if zeroed_pairs else ''),
+                          flush=True)
                 window.zero_(); win_n = 0
             if rank == 0 and step and step % args.save_every == 0:
                 os.makedirs(ckpt_dir, exist_ok=True)
@@ -446,6 +456,20 @@ def train(args):
     if rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)
         torch.save(step_fn.state_dict(), ckpt)          # Save the final model (:389)
+    if world > 1 and batch is not None and getattr(args, 'exchange_report', True):
+        # self-diagnosing multi-GPU run (dist.exchange_report): what the gradient exchange cost, from extra steps AFTER training
+        # on the last batch.  Those steps are real optimizer steps: the trained state is snapshotted and put back on every rank.
+        import copy
+        import json
+        snap = copy.deepcopy(step_fn.state_dict())
+
+        def run_steps(n):
+            for _ in range(n):
+                step_fn(batch)
+        rep = uh_dist.exchange_report(step_fn.averager, run_steps, ms_per_step=None)
+        step_fn.load_state_dict(snap)
+        if rank == 0:
+            print('===> exchange (world %d, %s): %s' % (world, torch.distributed.get_backend(), json.dumps(rep)), flush=True)
     return step_fn
 
 
@@ -477,19 +501,22 @@ class TestHomography(object):
         disk = None
         num_test_data = a.num_test_data
         if getattr(a, 'data_path', '') and getattr(a, 'test_filenames_file', ''):
-            # the reference's test Dataloader (:138-148, :441): disjoint augmentation, no shuffling
+            # the reference's test Dataloader (:138-148, :404): disjoint augmentation.  The reference passes shuffle=True there (its
+            # "# No shuffle" comment is wrong), so its 3 epochs draw from a shuffling queue; the statistics are the same in
+            # expectation.  Default here: the file list IN ORDER (every pair exactly three times, reproducible figures);
+            # --test_shuffle True = the reference's shuffled stream
             prm = uh_data.dataloader_params(data_path=a.data_path, filenames_file=a.test_filenames_file,
                                             pts1_file=a.test_pts1_file, gt_file=a.test_gt_file, mode='test',
                                             batch_size=a.batch_size, img_h=a.img_h, img_w=a.img_w,
                                             patch_size=a.patch_size, augment_list=a.augment_list, do_augment=a.do_augment)
-            loader = uh_data.Dataloader(prm, shuffle=False, device=self.device, seed=a.seed)
+            loader = uh_data.Dataloader(prm, shuffle=bool(getattr(a, 'test_shuffle', False)), device=self.device, seed=a.seed)
             num_test_data = len(loader.names)
             if 0 < num_test_data < a.batch_size:                          # test_batch_size = min(n, batch_size) (:136)
                 loader.params = prm._replace(batch_size=num_test_data)
                 self.params = self.params._replace(batch_size=num_test_data)
                 a = argparse.Namespace(**dict(vars(a), batch_size=num_test_data))
 
-            disk = loader.stream()             # shuffle=False: consecutive batches walk the list in order, wrapping
+            disk = loader.stream()             # unshuffled: consecutive batches walk the list in order, wrapping
         steps_per_epoch = int(np.ceil(num_test_data / a.batch_size))
         num_steps = 3 * steps_per_epoch                                   # (:400-401)
         per_pair, per_step, total_fail, total_bounded = [], [], 0.0, 0.0

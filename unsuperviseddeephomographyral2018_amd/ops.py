@@ -621,47 +621,11 @@ def photometric_tail(pts1, h4p, U, I2, patch_indices, patch_size, fused_patch=Fa
 # ------------------------------------------------------------------------------------------------
 class _ConvBiasReLU(torch.autograd.Function):
     """relu(conv2d(x, w) + b) with the conv on stock MIOpen and the bias+ReLU epilogue (and its backward, including
-    the bias gradient) as one HIP pass each (csrc/uh_epilogue.hip).  Activations are channels_last (NHWC storage)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, padding):
-        lib = _lib.load()
-        # (PyTorch-ROCm's fused aten::miopen_convolution_relu was measured as a replacement for conv + this pass in round 5:
-        #  miopenStatusUnknownError on channels_last inputs at batch 64, and 0.8 - 2.3 x the time of this route on NCHW copies:
-        #  profiles/r05_conv_relu_probe.jsonl, DESIGN.md 3.8)
-        y = torch.nn.functional.conv2d(x, weight, None, 1, padding)
-        if not y.is_contiguous(memory_format=torch.channels_last):
-            y = y.contiguous(memory_format=torch.channels_last)
-        N, Cc, Hh, Ww = y.shape
-        _lib.check(lib.uh_bias_relu_forward(_ptr(y), _ptr(_f32(bias, 'bias')), N * Hh * Ww, Cc, _stream()),
-                   'uh_bias_relu_forward')
-        ctx.save_for_backward(x, weight, y)
-        ctx.padding = padding
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        lib = _lib.load()
-        x, weight, y = ctx.saved_tensors
-        N, Cc, Hh, Ww = y.shape
-        gy = gy.contiguous(memory_format=torch.channels_last)
-        g = torch.empty_like(y, memory_format=torch.channels_last)
-        db = torch.empty((Cc,), dtype=torch.float32, device=y.device)
-        npix = N * Hh * Ww
-        nbytes = lib.uh_bias_relu_backward_workspace_bytes(npix, Cc)
-        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=y.device)
-        _lib.check(lib.uh_bias_relu_backward(_ptr(y), _ptr(gy), _ptr(g), _ptr(db), _ptr(ws), nbytes, npix, Cc, _stream()),
-                   'uh_bias_relu_backward')
-        p = ctx.padding
-        dx, dw, _ = torch.ops.aten.convolution_backward(
-            g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
-
-
-class _ConvBiasReLUBits(torch.autograd.Function):
-    """_ConvBiasReLU with the backward's ReLU mask kept as one bit per element (uh_bias_relu_forward_bits): the backward reads
-    gy + bits instead of gy + y (12 -> 8 B/element)."""
+    the bias gradient) as one HIP pass each (csrc/uh_epilogue.hip).  Activations are channels_last (NHWC storage).  The
+    backward's ReLU mask is kept as one bit per element: it reads gy + bits, not gy + y (12 -> 8 B/element).
+    (PyTorch-ROCm's fused aten::miopen_convolution_relu was measured as a replacement for conv + this pass in round 5:
+    miopenStatusUnknownError on channels_last inputs at batch 64, and 0.8 - 2.3 x the time of this route on NCHW copies:
+    profiles/r05_conv_relu_probe.jsonl)"""
 
     @staticmethod
     def forward(ctx, x, weight, bias, padding):
@@ -671,8 +635,8 @@ class _ConvBiasReLUBits(torch.autograd.Function):
             y = y.contiguous(memory_format=torch.channels_last)
         N, Cc, Hh, Ww = y.shape
         mask = torch.empty((lib.uh_relu_mask_bytes(N * Hh * Ww, Cc),), dtype=torch.uint8, device=y.device)
-        _lib.check(lib.uh_bias_relu_forward_bits(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(mask), N * Hh * Ww, Cc, _stream()),
-                   'uh_bias_relu_forward_bits')
+        _lib.check(lib.uh_bias_relu_forward(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(mask), N * Hh * Ww, Cc, _stream()),
+                   'uh_bias_relu_forward')
         ctx.save_for_backward(x, weight, mask)
         ctx.padding, ctx.shape = padding, (N, Cc, Hh, Ww)
         return y
@@ -686,70 +650,27 @@ class _ConvBiasReLUBits(torch.autograd.Function):
         g = torch.empty_like(gy, memory_format=torch.channels_last)
         db = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
         npix = N * Hh * Ww
-        nbytes = lib.uh_bias_relu_backward_bits_workspace_bytes(npix, Cc)
+        nbytes = lib.uh_bias_relu_backward_workspace_bytes(npix, Cc)
         ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=gy.device)
-        _lib.check(lib.uh_bias_relu_backward_bits(_ptr(mask), _ptr(gy), _ptr(g), _ptr(db), _ptr(ws), nbytes, npix, Cc, _stream()),
-                   'uh_bias_relu_backward_bits')
+        _lib.check(lib.uh_bias_relu_backward(_ptr(mask), _ptr(gy), _ptr(g), _ptr(db), _ptr(ws), nbytes, npix, Cc, _stream()),
+                   'uh_bias_relu_backward')
         p = ctx.padding
         dx, dw, _ = torch.ops.aten.convolution_backward(
             g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
             [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
         return dx, dw, (db if ctx.needs_input_grad[2] else None), None
-
-
-def _epi_bits():
-    """UH_EPI_BITS=0: the round 1-5 epilogues (the backward re-reads the activation); default: the bit-mask epilogues."""
-    import os
-    return os.environ.get('UH_EPI_BITS', '1') != '0'
 
 
 def conv_bias_relu(x, weight, bias, padding=1):
     """relu(conv2d(x, weight, bias, stride 1, padding)) -- homography_model.py:88-95 (_conv2d without batch norm)."""
-    return (_ConvBiasReLUBits if _epi_bits() else _ConvBiasReLU).apply(x, weight, bias, padding)
+    return _ConvBiasReLU.apply(x, weight, bias, padding)
 
 
 class _ConvBiasReLUPool(torch.autograd.Function):
-    """max_pool2d(relu(conv2d(x, w) + b), 2, 2): the epilogue also produces the pooled map, and its backward routes the
-    pooled gradient straight to the conv output (no full-resolution gradient of the pool in between)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, padding):
-        lib = _lib.load()
-        y = torch.nn.functional.conv2d(x, weight, None, 1, padding)
-        if not y.is_contiguous(memory_format=torch.channels_last):
-            y = y.contiguous(memory_format=torch.channels_last)
-        N, Cc, Hh, Ww = y.shape
-        pooled = torch.empty((N, Cc, Hh // 2, Ww // 2), dtype=torch.float32, device=y.device,
-                             memory_format=torch.channels_last)
-        _lib.check(lib.uh_bias_relu_pool_forward(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(pooled), N, Hh, Ww, Cc, _stream()),
-                   'uh_bias_relu_pool_forward')
-        ctx.save_for_backward(x, weight, y)
-        ctx.padding = padding
-        return pooled
-
-    @staticmethod
-    def backward(ctx, gp):
-        lib = _lib.load()
-        x, weight, y = ctx.saved_tensors
-        N, Cc, Hh, Ww = y.shape
-        gp = gp.contiguous(memory_format=torch.channels_last)
-        g = torch.empty_like(y, memory_format=torch.channels_last)
-        db = torch.empty((Cc,), dtype=torch.float32, device=y.device)
-        nbytes = lib.uh_bias_relu_pool_backward_workspace_bytes(N, Hh, Ww, Cc)
-        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=y.device)
-        _lib.check(lib.uh_bias_relu_pool_backward(_ptr(y), _ptr(gp), _ptr(g), _ptr(db), _ptr(ws), nbytes, N, Hh, Ww, Cc,
-                                                  _stream()), 'uh_bias_relu_pool_backward')
-        p = ctx.padding
-        dx, dw, _ = torch.ops.aten.convolution_backward(
-            g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
-
-
-class _ConvBiasReLUPoolBits(torch.autograd.Function):
-    """_ConvBiasReLUPool with the routing of the pooled gradient kept as 4 bits per pooled element: relu(conv + b) is never
-    written back at full resolution (the conv output is released right after the forward) and the backward reads
-    gpooled + bits (9 -> 5 B per conv-output element each way)."""
+    """max_pool2d(relu(conv2d(x, w) + b), 2, 2): the epilogue produces the pooled map directly, and its backward routes the
+    pooled gradient straight to the conv output (no full-resolution gradient of the pool in between).  The routing is kept as
+    4 bits per pooled element: relu(conv + b) is never written back at full resolution (the conv output is released right
+    after the forward) and the backward reads gpooled + bits (9 -> 5 B per conv-output element each way)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, padding):
@@ -762,8 +683,8 @@ class _ConvBiasReLUPoolBits(torch.autograd.Function):
                              memory_format=torch.channels_last)
         need_bw = any(ctx.needs_input_grad[:3])
         mask = torch.empty((lib.uh_pool_mask_bytes(N, Hh, Ww, Cc),), dtype=torch.uint8, device=y.device) if need_bw else None
-        _lib.check(lib.uh_bias_relu_pool_forward_bits(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(pooled), _ptr(mask), N, Hh, Ww, Cc,
-                                                      _stream()), 'uh_bias_relu_pool_forward_bits')
+        _lib.check(lib.uh_bias_relu_pool_forward(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(pooled), _ptr(mask), N, Hh, Ww, Cc,
+                                                      _stream()), 'uh_bias_relu_pool_forward')
         if need_bw:
             ctx.save_for_backward(x, weight, mask)
         ctx.padding, ctx.shape = padding, (N, Cc, Hh, Ww)
@@ -779,8 +700,8 @@ class _ConvBiasReLUPoolBits(torch.autograd.Function):
         db = torch.empty((Cc,), dtype=torch.float32, device=gp.device)
         nbytes = lib.uh_bias_relu_pool_backward_workspace_bytes(N, Hh, Ww, Cc)
         ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=gp.device)
-        _lib.check(lib.uh_bias_relu_pool_backward_bits(_ptr(mask), _ptr(gp), _ptr(g), _ptr(db), _ptr(ws), nbytes, N, Hh, Ww, Cc,
-                                                       _stream()), 'uh_bias_relu_pool_backward_bits')
+        _lib.check(lib.uh_bias_relu_pool_backward(_ptr(mask), _ptr(gp), _ptr(g), _ptr(db), _ptr(ws), nbytes, N, Hh, Ww, Cc,
+                                                       _stream()), 'uh_bias_relu_pool_backward')
         p = ctx.padding
         dx, dw, _ = torch.ops.aten.convolution_backward(
             g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
@@ -790,4 +711,4 @@ class _ConvBiasReLUPoolBits(torch.autograd.Function):
 
 def conv_bias_relu_pool(x, weight, bias, padding=1):
     """max_pool2d(relu(conv2d(x, weight, bias)), 2, 2) -- _conv2d + _maxpool2d (homography_model.py:88-105); H, W even."""
-    return (_ConvBiasReLUPoolBits if _epi_bits() else _ConvBiasReLUPool).apply(x, weight, bias, padding)
+    return _ConvBiasReLUPool.apply(x, weight, bias, padding)
