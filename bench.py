@@ -202,11 +202,11 @@ def reference_schedule_result():
                'data': 'clean in-HBM pool of 65 536 synthetic pairs, augment_list = [normalize]'}
     except Exception:
         return None
-    f2 = os.path.join(ROOT, 'profiles', 'r05_train_from_disk_reference_schedule.txt')
+    f2 = os.path.join(ROOT, 'profiles', 'r06_train_from_disk_reference_schedule.txt')
     try:
         rows = [json.loads(l[len('RESULT '):]) for l in open(f2) if l.startswith('RESULT ')]
         out['from_jpeg_files_with_augmentation'] = {
-            'file': 'profiles/r05_train_from_disk_reference_schedule.txt', 'note': 'read from the committed log, not measured in this run',
+            'file': 'profiles/r06_train_from_disk_reference_schedule.txt', 'note': 'read from the committed log, not measured in this run',
             'results': [{k: r[k] for k in ('files', 'train_do_augment', 'test_do_augment', 'steps', 'train_pairs', 'mean_corner_error_px',
                                            'fail_percent', 'per_pair_median_px')} for r in rows]}
     except Exception:

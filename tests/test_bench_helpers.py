@@ -83,7 +83,7 @@ def test_reference_schedule_result_is_read_from_the_committed_log(bench):
     # round 5: the same schedule FROM JPEG FILES through Dataloader + uh_prepare_inputs, tested with and without the reference's
     # disjoint test augmentation -- both rows are carried, neither is measured in the bench run
     d = r['from_jpeg_files_with_augmentation']
-    assert d['file'] == 'profiles/r05_train_from_disk_reference_schedule.txt' and 'not measured in this run' in d['note']
+    assert d['file'] == 'profiles/r06_train_from_disk_reference_schedule.txt' and 'not measured in this run' in d['note']
     rows = {row['test_do_augment']: row for row in d['results']}
     assert set(rows) == {0.0, 0.5} and all(row['steps'] == 150000 and row['files'] == 'jpg' for row in rows.values())
     assert rows[0.0]['mean_corner_error_px'] < 6.0 and rows[0.0]['fail_percent'] < 0.5           # the producers are sound ...

@@ -26,35 +26,44 @@ namespace uh {
 
 constexpr int EPI_BLOCKS = 1024;     // upper bound of the grid; every thread keeps ONE channel quad (1024 % C == 0)
 
-// db[c] = sum over blocks of partial[blk][c] in fixed order.  One block of 1024 threads: thread = (row r, channel c),
-// R = 1024 / C rows walk the partial blocks with stride R (coalesced: a wave reads 64 consecutive channels), the R row
-// sums of a channel then meet in LDS and are added in f64.
+// db[c] = sum over blocks of partial[blk][c] in fixed order.  Block b of the grid owns FIN_CH consecutive channels; its 1024
+// threads are (row r = tid / FIN_CH, channel j = tid % FIN_CH): a thread adds rows r, r + R, r + 2R ... (R = 1024 / FIN_CH rows, at
+// most EPI_BLOCKS / R = 8 of them, all loads in flight at once), the R row sums of a channel then meet in LDS and are added in
+// f64 in a fixed two-level order.  (Rounds 2-5 ran this as ONE block walking 64 - 128 rows per thread: 6.1 us per launch, eight launches
+// per step; C / 8 blocks walk 8 rows each.)
+constexpr int FIN_CH = 8;
 __global__ __launch_bounds__(1024) void bias_grad_finish_kernel(const float* __restrict__ partial, float* __restrict__ db,
                                                                 int nblk, int C) {
     __shared__ float sm[1024];
-    const int c = threadIdx.x % C, r = threadIdx.x / C, R = 1024 / C;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int b = r;
-    // 16 loads in flight (a thread walks up to 64 rows; four at a time cost one memory latency per four rows: 10 us per
-    // launch, 8 launches per step).  Same four accumulators, same order of additions as the loops below: same bits.
-    for (; b + 15 * R < nblk; b += 16 * R) {
-        float v[16];
+    const int cb = C < FIN_CH ? C : FIN_CH;                 // channels of this block (C = 4: one block of four)
+    const int j = threadIdx.x % cb, r = threadIdx.x / cb, R = 1024 / cb;
+    const int c = blockIdx.x * cb + j;
+    float v[EPI_BLOCKS / (1024 / FIN_CH)];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = partial[(size_t)(b + j * R) * C + c];
+    for (int k = 0; k < EPI_BLOCKS / (1024 / FIN_CH); ++k) {
+        const int row = r + k * R;
+        v[k] = row < nblk ? partial[(size_t)row * C + c] : 0.f;
+    }
+    float a = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; j += 4) { a0 += v[j]; a1 += v[j + 1]; a2 += v[j + 2]; a3 += v[j + 3]; }
-    }
-    for (; b + 3 * R < nblk; b += 4 * R) {
-        a0 += partial[(size_t)b * C + c]; a1 += partial[(size_t)(b + R) * C + c];
-        a2 += partial[(size_t)(b + 2 * R) * C + c]; a3 += partial[(size_t)(b + 3 * R) * C + c];
-    }
-    for (; b < nblk; b += R) a0 += partial[(size_t)b * C + c];
-    sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    for (int k = 0; k < EPI_BLOCKS / (1024 / FIN_CH); ++k) a += v[k];
+    sm[threadIdx.x] = a;
     __syncthreads();
-    if ((int)threadIdx.x < C) {
+    // R row sums per channel -> R / 8 group sums (f64, rows in order) -> one sum (groups in order): two short serial chains
+    __shared__ double sg[1024 / 8];
+    const int G = R / 8;
+    if ((int)threadIdx.x < G * cb) {
+        const int g = threadIdx.x / cb;
         double t = 0.0;
-        for (int k = 0; k < R; ++k) t += (double)sm[k * C + threadIdx.x];
-        db[threadIdx.x] = (float)t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += (double)sm[(g * 8 + k) * cb + j];
+        sg[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cb) {
+        double t = 0.0;
+        for (int g = 0; g < G; ++g) t += sg[g * cb + threadIdx.x];
+        db[c] = (float)t;
     }
 }
 
@@ -231,7 +240,7 @@ extern "C" int uh_bias_relu_backward(const void* mask, const float* gy, float* g
                  reinterpret_cast<const float4*>(gy), reinterpret_cast<float4*>(g), (float*)workspace, n4, C / 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(C < FIN_CH ? 1 : C / FIN_CH), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
     return (int)hipGetLastError();
 }
 
@@ -277,6 +286,6 @@ extern "C" int uh_bias_relu_pool_backward(const void* mask, const float* gpooled
                  reinterpret_cast<const float4*>(gpooled), reinterpret_cast<float4*>(g), (float*)workspace, nq, H / 2, W / 2, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(C < FIN_CH ? 1 : C / FIN_CH), dim3(1024), 0, s, (const float*)workspace, dbias, (int)grid, C);
     return (int)hipGetLastError();
 }
