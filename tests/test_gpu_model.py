@@ -171,10 +171,17 @@ def test_train_step_overfits_fixed_batch(pkg, dev):
     assert np.isfinite(losses).all()
     assert np.mean(losses[-10:]) < 0.9 * np.mean(losses[:10]), (losses[:3], losses[-3:])
     assert step.global_step == 60
+    # the Adam update is TF1's: the fused optimizer was handed the per-step eps of the 60th update (tests/test_optimizer.py)
+    assert step.adam_t == 60 and step.opt.param_groups[0]['eps'] == drv.tf_adam_eps(60)
+    assert all(float(st['step']) == 60.0 for st in step.opt.state.values())
     sd = step.state_dict()
     step2 = drv.TrainStep(args, dev, world=1)
     step2.load_state_dict(sd)
-    assert step2.global_step == 60
+    assert step2.global_step == 60 and step2.adam_t == 60
+    del sd['adam_t']                                            # a checkpoint of rounds 1-5: the counter comes from the optimizer state
+    step3 = drv.TrainStep(args, dev, world=1)
+    step3.load_state_dict(sd)
+    assert step3.adam_t == 60
 
 
 def test_supervised_mode_and_test_statistics(pkg, dev):
@@ -462,7 +469,7 @@ def test_step_graph_resume_keeps_the_adam_state(pkg, dev):
     coordinate: the two runs would differ by orders of magnitude more than the tolerance here."""
     hm, synthetic, drv = pkg
     common = ['--batch_size', str(B), '--img_h', str(H), '--img_w', str(W), '--patch_size', str(P), '--rho', str(RHO),
-              '--loss_type', 'l1_loss', '--lr', '1e-4']
+              '--loss_type', 'l1_loss', '--lr', '1e-4', '--tf_adam_epsilon', 'False']      # the graph route keeps torch's constant eps
     batch = synthetic.make_batch(B, H, W, P, RHO, seed=31, device=dev)
     torch.manual_seed(0)
     first = drv.TrainStep(drv.build_parser().parse_args(common), dev, 1)

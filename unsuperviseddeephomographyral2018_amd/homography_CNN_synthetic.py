@@ -90,6 +90,9 @@ def build_parser():
                    help='train mode: a pair whose d loss / d pred_h4p is NaN / Inf (degenerate predicted corners) contributes '
                         'no gradient instead of poisoning every variable (UH_DLT_ZERO_NONFINITE_GRAD).  False = the '
                         'reference\'s behaviour: tf.matrix_solve + autodiff pass the NaN on.  The log line counts the pairs.')
+    p.add_argument('--tf_adam_epsilon', type=str2bool, default='True',
+                   help='Adam update as tf.train.AdamOptimizer applies it (epsilon = the paper\'s "epsilon hat": homography_CNN_synthetic.tf_adam_eps); '
+                        'False = torch.optim.Adam\'s constant eps (rounds 1-5).  --step_graph always uses the latter')
     p.add_argument('--tunable_gemm', type=str2bool, default='True',
                    help='PyTorch TunableOp for the fully connected GEMMs (dist.tune_gemms): the first call of each GEMM shape benchmarks '
                         'the rocBLAS / hipBLASLt candidates, as cudnn.benchmark does for the convs (~3 s once per host; fc1 forward '
@@ -129,6 +132,15 @@ def staircase_lr(lr, step, decay_steps, decay_rate=0.96):
     return lr * decay_rate ** (step // int(decay_steps))
 
 
+def tf_adam_eps(t, eps_hat=1e-8, beta2=0.999):
+    """The `eps` that makes torch.optim.Adam's t-th update tf.train.AdamOptimizer's (the reference's optimizer, :183).  TF1 applies
+    lr_t * m / (sqrt(v) + eps_hat) with lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) -- its epsilon is the paper's "epsilon hat";
+    torch applies lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps).  The two coincide iff
+    eps = eps_hat / sqrt(1 - beta2^t): 31.6 eps_hat at t = 1, -> eps_hat as t grows.  (With a constant eps = 1e-8 torch's effective
+    epsilon-hat is up to 31.6 x smaller; it only matters for variables whose gradients are ~1e-8, but it is the reference's rule.)"""
+    return eps_hat / math.sqrt(1.0 - beta2 ** int(t))
+
+
 class TrainStep(object):
     """One tower: shared variables + Adam + (for world > 1) overlapped RCCL gradient averaging."""
 
@@ -147,6 +159,7 @@ class TrainStep(object):
             self.model_rng_seed = uh_dist.seed_tower_rng(getattr(args, 'seed', 0), self.rank)
         self.decay_steps = decay_steps_for(args.lr, args.min_lr)
         self.global_step = 0
+        self.adam_t = 0                                    # Adam updates applied so far (TF's beta-power accumulators; survives --retrain)
         # world == 1: no exchange step -> no flat buckets: autograd hands each parameter its gradient directly (no
         # 137 MB zero fill + read-modify-write accumulation per step)
         self.averager = uh_dist.GradAverager(self.net, world) if world > 1 else None
@@ -170,6 +183,9 @@ class TrainStep(object):
         self.opt = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr0,
                                     betas=(0.9, 0.999), eps=1e-8, **kw)
         self._graph = None
+        # the reference's Adam is TF1's ("epsilon hat" form): torch's eps is set per step so that the update is the same (tf_adam_eps).
+        # Not in the whole-step hipGraph, where Adam's eps is a captured constant: that mode keeps torch's rule.
+        self.tf_adam_epsilon = bool(getattr(args, 'tf_adam_epsilon', True)) and not self.step_graph
         self.model_params = homography_model_params(
             mode=args.mode, batch_size=int(args.batch_size / world), patch_size=args.patch_size,
             img_h=args.img_h, img_w=args.img_w, loss_type=args.loss_type, use_batch_norm=args.use_batch_norm,
@@ -292,6 +308,7 @@ class TrainStep(object):
                     self._static[k].copy_(v)
             self._graph.replay()
             self.global_step += 1
+            self.adam_t += 1
             return self._graph_model                     # its tensors are the graph's static outputs
         if getattr(self.args, 'graph_tail', False) and self.device.type == 'cuda':
             # stream capture needs a real (non-NULL) stream: run the whole step on a private one
@@ -308,6 +325,8 @@ class TrainStep(object):
         lr = self.learning_rate()
         for g in self.opt.param_groups:
             g['lr'] = lr
+            if self.tf_adam_epsilon:
+                g['eps'] = tf_adam_eps(self.adam_t + 1, 1e-8, g['betas'][1])
         self._zero_or_reset()
         model = HomographyModel(self.model_params, *synthetic.model_args(batch), reuse_variables=True,
                                 net=self.net, fused_patch=self.args.fused_patch, solve_f64=self.args.solve_f64,
@@ -318,10 +337,11 @@ class TrainStep(object):
             self.averager.finish()
         self.opt.step()
         self.global_step += 1
+        self.adam_t += 1
         return model
 
     def state_dict(self):
-        return {'net': self.net.state_dict(), 'opt': self.opt.state_dict(), 'global_step': self.global_step}
+        return {'net': self.net.state_dict(), 'opt': self.opt.state_dict(), 'global_step': self.global_step, 'adam_t': self.adam_t}
 
     def load_state_dict(self, sd, retrain=False):
         self.net.load_state_dict(sd['net'])
@@ -336,6 +356,12 @@ class TrainStep(object):
             if torch.is_tensor(st.get('step')) and self.device.type == 'cuda':
                 st['step'] = st['step'].to(device=self.device, dtype=torch.float32)
         self.global_step = 0 if retrain else sd['global_step']        # (:314-317)
+        # TF restores Adam's beta-power accumulators with the other variables: --retrain resets the step counter, not them
+        if 'adam_t' in sd:
+            self.adam_t = int(sd['adam_t'])
+        else:                                                          # a checkpoint of rounds 1-5: read it from the optimizer state
+            steps = [st['step'] for st in self.opt.state.values() if 'step' in st]
+            self.adam_t = int(float(steps[0])) if steps else 0
         # a step graph captured BEFORE this call replays against the old lr / state tensors: capture again on the next step
         self._graph = None
         self._static = None
