@@ -334,3 +334,19 @@ def test_gloo_group_formation_keeps_stdout_clean():
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, se[-2000:]
         assert so == 'RANK %d OF 2 SUM 3\n' % r, 'stdout of rank %d is not clean: %r' % (r, so)
+
+
+def test_tunableop_cache_dir_must_be_private(tmp_path, monkeypatch):
+    """dist.tune_gemms' results file lives in a directory only this user can touch: a directory with group / world
+    permission bits, a symlink, or somebody else's directory is replaced by a fresh mkdtemp one."""
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    good = tmp_path / 'good'; good.mkdir(mode=0o700)
+    os.chmod(good, 0o700)
+    assert D._private_dir_or_fresh(str(good)) == str(good)
+    loose = tmp_path / 'loose'; loose.mkdir(); os.chmod(loose, 0o777)
+    got = D._private_dir_or_fresh(str(loose))
+    assert got != str(loose) and os.path.isdir(got) and (os.stat(got).st_mode & 0o077) == 0
+    link = tmp_path / 'link'; link.symlink_to(good)
+    assert D._private_dir_or_fresh(str(link)) != str(link)                # lstat: a symlink is not a directory of ours
+    monkeypatch.setattr(os, 'getuid', lambda: os.stat(str(good)).st_uid + 1)
+    assert D._private_dir_or_fresh(str(good)) != str(good)                # owned by another user

@@ -157,14 +157,14 @@ def tune_gemms(max_ms_per_solution=15, max_iterations=20, filename=None):
 
 
 def _private_dir_or_fresh(d):
-    """`d` if it is a real directory owned by this user that nobody else can write to; otherwise a fresh mkdtemp directory (no
+    """`d` if it is a real directory owned by this user with no group / world permission bits (0o700); otherwise a fresh mkdtemp directory (no
     caching across processes, but never a results file another user could have planted: makedirs(exist_ok=True) accepts a
     directory somebody else created first in a world-writable $TMPDIR)."""
     import stat
     import tempfile
     try:
         st = os.lstat(d)
-        if stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o022) == 0:
+        if stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0:
             return d
     except OSError:
         pass
