@@ -63,7 +63,7 @@ def _worker(rank, world, port, q, loss_type, dropout_p):
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     import copy
     from unsuperviseddeephomographyral2018_amd import _lib, dist as D, synthetic
-    from unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic import TrainStep
+    from unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic import TrainStep, tf_adam_eps
     from unsuperviseddeephomographyral2018_amd.homography_model import HomographyModel, VGGRegressor
     _lib.load()
     # MIOpen's default conv solvers are not run-to-run reproducible (split-K / atomic accumulation): with
@@ -134,8 +134,9 @@ def _worker(rank, world, port, q, loss_type, dropout_p):
         two = fresh(B // world)                             # its model_params carry the per-tower batch size
         g_two = None
         for it in range(STEPS):
-            for g in two.opt.param_groups:
+            for g in two.opt.param_groups:                  # what TrainStep._step sets: staircase lr + TF's epsilon-hat rule
                 g['lr'] = two.learning_rate()
+                g['eps'] = tf_adam_eps(it + 1, 1e-8, g['betas'][1])
             two.opt.zero_grad(set_to_none=True)
             tower_losses = []
             for k in range(world):
