@@ -363,3 +363,28 @@ def test_train_two_ranks_reduces_its_monitors_at_log_steps_only(tmp_path):
     assert rep['ms_per_step_with_exchange'] > 0 and rep['ms_per_step_no_exchange'] > 0 and len(rep['buckets']) == 2
     assert abs(rep['exchange_cost_ms_per_step'] - (rep['ms_per_step_with_exchange'] - rep['ms_per_step_no_exchange'])) < 2e-3
     assert out[1]['stdout'].count('Train: step') == 0              # rank 0 alone prints
+
+
+def test_readme_command_line_with_num_gpus_2_runs_end_to_end(tmp_path):
+    """The reference README's first command line (README.md:125: `--mode train --lr 5e-4 --loss_type h_loss --visual True`) plus
+    `--num_gpus 2`, as a user would type it: the program re-executes itself under torch.distributed.run with two ranks (sharing
+    this box's GPU over gloo, and saying so), trains, logs from rank 0 and writes the checkpoint.  VERDICT r5 item 1."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic',
+           '--mode', 'train', '--lr', '5e-4', '--loss_type', 'h_loss', '--visual', 'True',          # README.md:125, verbatim
+           '--num_gpus', '2', '--batch_size', '8', '--num_total_steps', '3', '--log_every', '1', '--exchange_report', 'False',
+           '--tunable_gemm', 'False', '--model_dir', str(tmp_path / 'models')]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'world size: 2' in r.stdout and r.stdout.count('Train: step') == 3 and 'Train: step 2 ' in r.stdout
+    assert '--visual True' in r.stderr
+    if torch.cuda.device_count() < 2:
+        assert 'share the visible device(s) over gloo' in r.stderr
+    assert os.path.exists(str(tmp_path / 'models' / 'h_loss_normalize' / 'model.ckpt.pt'))
