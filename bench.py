@@ -193,12 +193,12 @@ def reference_schedule_result():
     without the reference's disjoint test augmentation (tools/train_from_disk.py)."""
     import re
     out = None
-    f = os.path.join(ROOT, 'profiles', 'r04_train_reference_schedule.txt')
+    f = os.path.join(ROOT, 'profiles', 'r06_train_reference_schedule.txt')
     try:
         txt = open(f).read()
         m = re.search(r'Average error: ([0-9.]+) \|Fail percent: ([0-9.]+)', txt)
         out = {'mean_corner_error_px': float(m.group(1)), 'fail_percent': float(m.group(2)), 'train_steps': 150000,
-               'file': 'profiles/r04_train_reference_schedule.txt', 'note': 'read from the committed log, not measured in this run',
+               'file': 'profiles/r06_train_reference_schedule.txt', 'note': 'read from the committed log, not measured in this run',
                'data': 'clean in-HBM pool of 65 536 synthetic pairs, augment_list = [normalize]'}
     except Exception:
         return None
