@@ -75,7 +75,7 @@ def test_warped_frame_equals_the_oracle_warp_up_to_the_uint8_cast(dev, uh_lib_pa
     got = G.warp_pairs(I, pts1, gt).cpu().numpy().astype(np.int32)
     Hm = O.solve_dlt_lapack64(pts1.cpu().numpy(), gt.cpu().numpy())
     theta = O.theta_from_H(Hm, W, H, np.float64)
-    ref = O.transformer(I.cpu().numpy().astype(np.float64), theta, (H, W), np.float64)
+    ref, _ = O.transformer(I.cpu().numpy().astype(np.float64), theta, (H, W), np.float64)
     want = np.clip(ref, 0, 255).astype(np.uint8).astype(np.int32)
     d = np.abs(got - want)
     assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
