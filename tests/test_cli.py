@@ -158,3 +158,23 @@ def test_find_percentile_equals_the_reference_function(cnn):
     # the test loop hands it a list of float32 scalars, like sess.run's h_loss values (:537)
     x32 = z['x_f32']
     np.testing.assert_array_equal(np.asarray(cnn.find_percentile([np.float32(v) for v in x32]), np.float64), z['y_f32'])
+
+
+def test_gen_synthetic_data_paths_follow_the_reference_defaults():
+    """gen_synthetic_data: default file names under data_path (utils/gen_synthetic_data.py:209-218) and the test-mode numbering
+    (:252-255: start_index = num_data, num_data = test_num_data, raw images from test_raw_data_path)."""
+    from unsuperviseddeephomographyral2018_amd import gen_synthetic_data as G
+    p = G.build_parser()
+    for f in ('--mode', '--color', '--raw_data_path', '--test_raw_data_path', '--data_path', '--I_dir', '--I_prime_dir', '--pts1_file',
+              '--test_pts1_file', '--num_data', '--test_num_data', '--gt_file', '--test_gt_file', '--filenames_file',
+              '--test_filenames_file', '--img_w', '--img_h', '--rho', '--patch_size', '--img_per_real', '--resume', '--start_index'):
+        assert _action(p, f) is not None, f                                # the reference's flags (its --visual / --debug / --artifact_mode aside)
+    d = p.parse_args(['--data_path', '/d/s'])
+    assert (d.mode, d.num_data, d.test_num_data, d.img_w, d.img_h, d.rho, d.patch_size, d.img_per_real, d.resume) == \
+        ('test', 100000, 5000, 320, 240, 45, 128, 2, 'N')                  # the reference's defaults (:190-199, :222-249)
+    a = G.resolve_paths(p.parse_args(['--data_path', '/d/s', '--mode', 'train', '--raw_data_path', '/raw']))
+    assert (a.I_dir, a.I_prime_dir) == ('/d/s/I', '/d/s/I_prime') and a.start_index == 0 and a.raw_data_path == '/raw'
+    assert (a.pts1_file, a.gt_file, a.filenames_file) == ('/d/s/pts1.txt', '/d/s/gt.txt', '/d/s/train_synthetic.txt')
+    t = G.resolve_paths(p.parse_args(['--data_path', '/d/s', '--num_data', '70', '--test_num_data', '9', '--test_raw_data_path', '/rt']))
+    assert (t.start_index, t.num_data, t.raw_data_path) == (70, 9, '/rt')
+    assert (t.test_pts1_file, t.test_gt_file, t.test_filenames_file) == ('/d/s/test_pts1.txt', '/d/s/test_gt.txt', '/d/s/test_synthetic.txt')
