@@ -80,7 +80,7 @@ def test_readme_command_lines_parse_verbatim(ref_cli, cnn):
     # flags nobody set produce no note (save_visual defaults to True in the reference)
     assert cnn.unsupported_flag_notes(parser.parse_args(cmds[3]['argv']), cmds[3]['argv']) == []
     argv = ['--mode', 'test', '--save_visual', 'True', '--I_dir', '/d/I/', '--I_prime_dir=/d/I_prime/']
-    assert len(cnn.unsupported_flag_notes(parser.parse_args(argv), argv)) == 3
+    assert len(cnn.unsupported_flag_notes(parser.parse_args(argv), argv)) == 2      # --save_visual is honoured (test mode), not noted
 
 
 def test_num_gpus_is_never_silently_ignored(monkeypatch):
@@ -178,3 +178,27 @@ def test_gen_synthetic_data_paths_follow_the_reference_defaults():
     t = G.resolve_paths(p.parse_args(['--data_path', '/d/s', '--num_data', '70', '--test_num_data', '9', '--test_raw_data_path', '/rt']))
     assert (t.start_index, t.num_data, t.raw_data_path) == (70, 9, '/rt')
     assert (t.test_pts1_file, t.test_gt_file, t.test_filenames_file) == ('/d/s/test_pts1.txt', '/d/s/test_gt.txt', '/d/s/test_synthetic.txt')
+
+
+def test_save_correspondences_img_draws_the_report_image(tmp_path, cnn):
+    """--save_visual (reference test loop :539-552 -> utils.save_correspondences_img / draw_matches, utils/utils.py:209-308), with
+    PIL: two frames side by side, predicted quadrilateral on the second, ground-truth quadrilaterals, four coloured matches."""
+    from PIL import Image
+    h, w = 60, 80
+    img1 = np.full((h, w, 3), 40, np.uint8); img2 = np.full((h, w, 3), 90, np.uint8)
+    c1 = np.array([[20, 15], [50, 15], [50, 45], [20, 45]], np.float32)
+    gt = np.array([[3, -2], [-4, 1], [2, 5], [-1, -3]], np.float32)
+    pred = gt + 2.0
+    path = cnn.save_correspondences_img(img1, img2, c1, c1 + gt, c1 + pred, str(tmp_path / 'report'), '0_l1_loss_loss_1.5.jpg')
+    assert os.path.exists(path) and path.endswith('report/0_l1_loss_loss_1.5.jpg')
+    out = np.asarray(Image.open(path)).astype(int)
+    assert out.shape == (h, 2 * w, 3)
+    assert abs(out[2, 2] - 40).max() <= 6 and abs(out[2, w + 2] - 90).max() <= 6            # the two frames, untouched corners
+    # the ground-truth edge on the first frame (blue-ish (2, 10, 240), width 3) and the prediction on the second ((5, 225, 225))
+    assert out[30, 20, 2] > 150 and out[30, 20, 0] < 90                                      # its left edge (no match line crosses it)
+    x, y = int(w + (c1 + pred)[0, 0] + 10), int((c1 + pred)[0, 1])
+    band = out[y - 3:y + 4, w + 25:w + 45].reshape(-1, 3)
+    assert ((band[:, 1] > 150) & (band[:, 2] > 150) & (band[:, 0] < 110)).any()
+    # denorm_img: the dataloader's constants, per channel and for gray
+    z = np.zeros((2, 2, 3)); assert np.allclose(cnn.denorm_img(z)[0, 0], [118.93, 113.97, 102.60])
+    assert np.allclose(cnn.denorm_img(np.ones((2, 2))), np.mean([118.93, 113.97, 102.60]) + np.mean([69.85, 68.81, 72.45]))

@@ -198,6 +198,18 @@ def test_supervised_mode_and_test_statistics(pkg, dev):
     assert float(m.h_loss.detach()) < first
     res = drv.TestHomography(args, step_fn=step).run()
     assert res['num_pairs'] == 3 * 2 * 8 and 0 <= res['fail_percent'] <= 100 and res['mean_corner_error'] > 0
+    # --save_visual (the reference's test-mode default, :539-552): one correspondence image per test step into --results_dir
+    import os
+    import tempfile
+    from PIL import Image
+    with tempfile.TemporaryDirectory() as td:
+        args.results_dir = os.path.join(td, 'report')
+        res2 = drv.TestHomography(args, step_fn=step).run(save_visual=True)
+        files = sorted(os.listdir(args.results_dir))
+        assert len(files) == 3 * 2 and all(f.endswith('.jpg') and '_h_loss_loss_' in f for f in files), files
+        assert files[0].startswith('0_') and any(f.startswith('8_') for f in files)        # named by step * batch_size
+        assert Image.open(os.path.join(args.results_dir, files[0])).size == (2 * W, H)
+        assert res2['mean_corner_error'] == res['mean_corner_error']
 
 
 @pytest.mark.parametrize('fused', [False, True])

@@ -64,12 +64,13 @@ def build_parser():
     p.add_argument('--filenames_file', type=str, default='', help='File that contains all names of files, for training')
     p.add_argument('--test_filenames_file', type=str, default='')
     # accepted for command-line compatibility (:64-65, :73-74).  --I_dir / --I_prime_dir are parsed and never read by the
-    # reference either (its Dataloader joins data_path + 'I/' / 'I_prime/', dataloader.py:143-144); --visual / --save_visual
-    # drive its matplotlib / cv2 side (:117, :334, :362-387, :539-567), which is outside the hot path: main() says so once
+    # reference either (its Dataloader joins data_path + 'I/' / 'I_prime/', dataloader.py:143-144); --visual drives its interactive
+    # matplotlib side (:117, :334, :362-387, :559-567), which is outside the hot path: main() says so once.  --save_visual is
+    # honoured in test mode (one correspondence image per step into --results_dir, :539-552, drawn with PIL)
     p.add_argument('--I_dir', type=str, default='', help='The training image path (unused, as in the reference: data_path + I/)')
     p.add_argument('--I_prime_dir', type=str, default='', help='The training image path (unused: data_path + I_prime/)')
     p.add_argument('--visual', type=str2bool, default='false', help='Visualize obtained images to debug (accepted; no plotting here)')
-    p.add_argument('--save_visual', type=str2bool, default='True', help='Save visual images for report (accepted; nothing is drawn here)')
+    p.add_argument('--save_visual', type=str2bool, default='True', help='Save visual images for report: test mode writes one correspondence image per step into --results_dir')
     p.add_argument('--img_w', type=int, default=WIDTH)
     p.add_argument('--img_h', type=int, default=HEIGHT)
     p.add_argument('--patch_size', type=int, default=PATCH_SIZE)
@@ -499,6 +500,44 @@ def train(args):
     return step_fn
 
 
+def denorm_img(img):
+    """utils.denorm_img (utils/utils.py:406-413): x * std + mean with the dataloader's constants (per channel, or their means for
+    a gray image)."""
+    mean, std = np.array(synthetic.MEAN_I), np.array(synthetic.STD_I)
+    if img.ndim == 2:
+        mean, std = mean.mean(), std.mean()
+    return img * std + mean
+
+
+def save_correspondences_img(img1, img2, corr1, corr2, pred_corr2, results_dir, img_name):
+    """utils.save_correspondences_img + draw_matches for four points (utils/utils.py:209-224,230-308) with PIL instead of cv2: the two
+    uint8 frames side by side, the predicted quadrilateral on the second frame, both ground-truth quadrilaterals, and the four
+    correspondences joined by coloured lines with a circle of radius 7 at each end.  -> the path written."""
+    from PIL import Image, ImageDraw
+    img1, img2 = np.asarray(img1, np.uint8), np.asarray(img2, np.uint8)
+    h = max(img1.shape[0], img2.shape[0])
+    canvas = np.zeros((h, img1.shape[1] + img2.shape[1], 3), np.uint8)
+    canvas[:img1.shape[0], :img1.shape[1]] = img1
+    canvas[:img2.shape[0], img1.shape[1]:] = img2
+    im = Image.fromarray(canvas)
+    d = ImageDraw.Draw(im)
+    off = np.array([img1.shape[1], 0])
+    quad = lambda pts: [tuple(int(v) for v in p) for p in np.asarray(pts).reshape(4, 2)] + [tuple(int(v) for v in np.asarray(pts).reshape(4, 2)[0])]
+    d.line(quad(np.asarray(pred_corr2).reshape(4, 2) + off), fill=(5, 225, 225), width=3)                # the prediction (:214)
+    d.line(quad(np.asarray(corr2).reshape(4, 2) + off), fill=(2, 10, 240), width=3)                     # ground truth, second frame (:275)
+    d.line(quad(corr1), fill=(2, 10, 240), width=3)                                                     # ... first frame (:276)
+    colors = [(255, 102, 255), (51, 153, 255), (102, 255, 255), (255, 255, 0)]                          # line_color_set (:217)
+    for k, (a, b) in enumerate(zip(np.asarray(corr1).reshape(4, 2), np.asarray(corr2).reshape(4, 2))):
+        e1 = tuple(int(v) for v in np.round(a)); e2 = tuple(int(v) for v in np.round(b) + off)
+        d.line([e1, e2], fill=colors[k], width=1)
+        for e in (e1, e2):
+            d.ellipse([e[0] - 7, e[1] - 7, e[0] + 7, e[1] + 7], outline=colors[k], width=1)
+    os.makedirs(results_dir, exist_ok=True)
+    path = os.path.join(results_dir, img_name)
+    im.save(path, quality=95)
+    return path
+
+
 class TestHomography(object):
     """Test-mode loop (:391-580): mean corner error (bounded RMSE), failure rate and percentiles."""
 
@@ -522,7 +561,9 @@ class TestHomography(object):
             img_w=args.img_w, loss_type=args.loss_type, use_batch_norm=args.use_batch_norm,
             augment_list=args.augment_list, leftright_consistent_weight=args.leftright_consistent_weight)
 
-    def run(self):
+    def run(self, save_visual=False):
+        """save_visual: write one correspondence image per test step into args.results_dir, as the reference's test loop does with
+        --save_visual True (:539-552).  The command line passes the flag; library callers (bench.py) leave it off."""
         a = self.args
         disk = None
         num_test_data = a.num_test_data
@@ -558,6 +599,13 @@ class TestHomography(object):
                 total_bounded += float(per_step[-1])
                 total_fail += float(m.num_fail)
                 per_pair.append(torch.sqrt(torch.mean((m.pred_h4p - m.gt) ** 2, dim=1)).cpu())
+                if save_visual:                                            # the first pair of the batch (:539-552)
+                    I_s = denorm_img(m.I[0].cpu().numpy()).clip(0, 255).astype(np.uint8)
+                    Ip_s = denorm_img(m.I_prime[0].cpu().numpy()).clip(0, 255).astype(np.uint8)
+                    p1 = m.pts_1[0].cpu().numpy().reshape(4, 2)
+                    name = '%d_%s_loss_%s.jpg' % (step * a.batch_size, a.loss_type, per_step[-1])
+                    save_correspondences_img(Ip_s, I_s, p1, p1 + m.gt[0].cpu().numpy().reshape(4, 2),
+                                             p1 + m.pred_h4p[0].cpu().numpy().reshape(4, 2), a.results_dir, name)
         self.net.train(was_training)
         if disk is not None:
             disk.close()
@@ -612,8 +660,6 @@ def unsupported_flag_notes(args, argv):
     if args.visual:
         notes.append('--visual True: the reference plots with matplotlib every step (:362-387, :559-567); there is no plotting side '
                      'here -- training / testing runs without it')
-    if '--save_visual' in given and args.save_visual and args.mode == 'test':
-        notes.append('--save_visual True: the reference writes correspondence JPEGs into --results_dir with cv2 (:539-552); not drawn here')
     for f in ('--I_dir', '--I_prime_dir'):
         if f in given:
             notes.append('%s: parsed and never read, exactly as in the reference (frames are data_path + I/ and I_prime/)' % f)
@@ -645,7 +691,7 @@ def main(argv=None):
             print('note: test mode evaluates on one GPU; --num_gpus / WORLD_SIZE %d does not change the statistics' % world,
                   file=sys.stderr, flush=True)
         if int(os.environ.get('RANK', '0')) == 0:
-            TestHomography(args).run()
+            TestHomography(args).run(save_visual=args.save_visual)
 
 
 if __name__ == '__main__':
