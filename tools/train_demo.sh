@@ -11,7 +11,7 @@ run() {  # name, loss, steps, extra
   timeout 900 python -m $M --mode train --loss_type $2 --batch_size 64 --num_total_steps $3 --log_every ${LOG:-2500} \
       --save_every 100000000 --model_dir /tmp/uh_models_$1 --data_pool ${POOL:-512} --texture multiscale $4 2>&1 \
       | grep -E "Train:|rror" | sed 's/rec_loss.*lr/lr/' >> $OUT
-  timeout 200 python -m $M --mode test --loss_type $2 --batch_size 64 --num_test_data 1024 --model_dir /tmp/uh_models_$1 --texture multiscale 2>&1 \
+  timeout 200 python -m $M --mode test --save_visual False --loss_type $2 --batch_size 64 --num_test_data 1024 --model_dir /tmp/uh_models_$1 --texture multiscale 2>&1 \
       | grep -E "Result|Average|ercentile|rror" >> $OUT
 }
 run unsup_lr1e-4 l1_loss ${STEPS:-30000} ""

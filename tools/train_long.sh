@@ -7,6 +7,6 @@ echo "=== unsup 100k : --loss_type l1_loss --lr 3e-4 --min_lr 2.7e-4 --batch_siz
 timeout 1500 python -m $M --mode train --loss_type l1_loss --batch_size 64 --num_total_steps 100000 --log_every 10000 \
     --save_every 100000000 --model_dir /tmp/uh_models_long --data_pool 1024 --texture multiscale --lr 3e-4 --min_lr 2.7e-4 2>&1 \
     | grep -E "Train:|rror|Decay" | sed 's/rec_loss.*lr/lr/' >> $OUT
-timeout 300 python -m $M --mode test --loss_type l1_loss --batch_size 64 --num_test_data 2048 --model_dir /tmp/uh_models_long --texture multiscale 2>&1 \
+timeout 300 python -m $M --mode test --save_visual False --loss_type l1_loss --batch_size 64 --num_test_data 2048 --model_dir /tmp/uh_models_long --texture multiscale 2>&1 \
     | grep -E "Result|Average|ercentile|rror" >> $OUT
 echo done

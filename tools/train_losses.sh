@@ -10,7 +10,7 @@ for L in rec_loss ssim_loss l1_smooth_loss ncc_loss l1_loss; do
   timeout 400 python -m $M --mode train --loss_type $L --batch_size 64 --num_total_steps 10000 --log_every 5000 \
       --save_every 100000000 --model_dir /tmp/uh_models_$L --data_pool 512 --texture multiscale --lr 3e-4 --min_lr 2.7e-4 2>&1 \
       | grep -E "Train:|rror" | sed 's/rec_loss.*lr/lr/' >> $OUT
-  timeout 200 python -m $M --mode test --loss_type $L --batch_size 64 --num_test_data 1024 --model_dir /tmp/uh_models_$L --texture multiscale 2>&1 \
+  timeout 200 python -m $M --mode test --save_visual False --loss_type $L --batch_size 64 --num_test_data 1024 --model_dir /tmp/uh_models_$L --texture multiscale 2>&1 \
       | grep -E "Result|Average|rror" >> $OUT
 done
 cat $OUT

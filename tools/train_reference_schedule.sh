@@ -15,6 +15,6 @@ timeout ${TRAIN_TIMEOUT:-1500} python -m $M --mode train --loss_type $LOSS --bat
     --save_every 100000000 --model_dir $MD --data_pool $POOL --texture multiscale --lr 1e-4 --min_lr .9e-4 2>&1 \
     | grep -E "Train:|rror|Decay" | sed 's/rec_loss.*lr/lr/' >> $OUT
 echo "=== training wall time: $(( $(date +%s) - t0 )) s" >> $OUT
-timeout 300 python -m $M --mode test --loss_type $LOSS --batch_size $BATCH --num_test_data 1024 --model_dir $MD --texture multiscale 2>&1 \
+timeout 300 python -m $M --mode test --save_visual False --loss_type $LOSS --batch_size $BATCH --num_test_data 1024 --model_dir $MD --texture multiscale 2>&1 \
     | grep -E "Result|Average|ercentile|rror" >> $OUT
 tail -8 $OUT

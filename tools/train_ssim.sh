@@ -10,7 +10,7 @@ for LR in "1e-4 9e-5" "3e-5 2.7e-5"; do
   timeout 300 python -m $M --mode train --loss_type ssim_loss --batch_size 64 --num_total_steps 8000 --log_every 2000 \
       --save_every 100000000 --model_dir /tmp/uh_models_ssim_$1 --data_pool 256 --texture multiscale --lr $1 --min_lr $2 2>&1 \
       | grep -E "Train:|rror" | sed 's/rec_loss.*lr/lr/' >> $OUT
-  timeout 200 python -m $M --mode test --loss_type ssim_loss --batch_size 64 --num_test_data 1024 --model_dir /tmp/uh_models_ssim_$1 --texture multiscale 2>&1 \
+  timeout 200 python -m $M --mode test --save_visual False --loss_type ssim_loss --batch_size 64 --num_test_data 1024 --model_dir /tmp/uh_models_ssim_$1 --texture multiscale 2>&1 \
       | grep -E "Result|Average|rror" >> $OUT
 done
 cat $OUT
