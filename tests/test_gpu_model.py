@@ -209,7 +209,7 @@ def test_supervised_mode_and_test_statistics(pkg, dev):
         assert len(files) == 3 * 2 and all(f.endswith('.jpg') and '_h_loss_loss_' in f for f in files), files
         assert files[0].startswith('0_') and any(f.startswith('8_') for f in files)        # named by step * batch_size
         assert Image.open(os.path.join(args.results_dir, files[0])).size == (2 * W, H)
-        assert res2['mean_corner_error'] == res['mean_corner_error']
+        assert abs(res2['mean_corner_error'] - res['mean_corner_error']) <= 1e-4 * res['mean_corner_error']      # same statistics (MIOpen's solvers are not bit-repeatable)
 
 
 @pytest.mark.parametrize('fused', [False, True])
