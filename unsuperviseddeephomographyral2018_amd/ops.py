@@ -634,10 +634,12 @@ class _ConvBiasReLU(torch.autograd.Function):
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
         N, Cc, Hh, Ww = y.shape
-        mask = torch.empty((lib.uh_relu_mask_bytes(N * Hh * Ww, Cc),), dtype=torch.uint8, device=y.device)
+        need_bw = any(ctx.needs_input_grad[:3])                # no_grad / frozen layer: no mask is written (mask == NULL)
+        mask = torch.empty((lib.uh_relu_mask_bytes(N * Hh * Ww, Cc),), dtype=torch.uint8, device=y.device) if need_bw else None
         _lib.check(lib.uh_bias_relu_forward(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(mask), N * Hh * Ww, Cc, _stream()),
                    'uh_bias_relu_forward')
-        ctx.save_for_backward(x, weight, mask)
+        if need_bw:
+            ctx.save_for_backward(x, weight, mask)
         ctx.padding, ctx.shape = padding, (N, Cc, Hh, Ww)
         return y
 
@@ -684,7 +686,7 @@ class _ConvBiasReLUPool(torch.autograd.Function):
         need_bw = any(ctx.needs_input_grad[:3])
         mask = torch.empty((lib.uh_pool_mask_bytes(N, Hh, Ww, Cc),), dtype=torch.uint8, device=y.device) if need_bw else None
         _lib.check(lib.uh_bias_relu_pool_forward(_ptr(y), _ptr(_f32(bias, 'bias')), _ptr(pooled), _ptr(mask), N, Hh, Ww, Cc,
-                                                      _stream()), 'uh_bias_relu_pool_forward')
+                                                 _stream()), 'uh_bias_relu_pool_forward')
         if need_bw:
             ctx.save_for_backward(x, weight, mask)
         ctx.padding, ctx.shape = padding, (N, Cc, Hh, Ww)
@@ -701,7 +703,7 @@ class _ConvBiasReLUPool(torch.autograd.Function):
         nbytes = lib.uh_bias_relu_pool_backward_workspace_bytes(N, Hh, Ww, Cc)
         ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=gp.device)
         _lib.check(lib.uh_bias_relu_pool_backward(_ptr(mask), _ptr(gp), _ptr(g), _ptr(db), _ptr(ws), nbytes, N, Hh, Ww, Cc,
-                                                       _stream()), 'uh_bias_relu_pool_backward')
+                                                  _stream()), 'uh_bias_relu_pool_backward')
         p = ctx.padding
         dx, dw, _ = torch.ops.aten.convolution_backward(
             g, x, weight, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
