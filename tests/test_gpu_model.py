@@ -612,3 +612,32 @@ def test_zeroed_pairs_counter_is_read_on_the_callers_stream_and_refuses_a_captur
         g.replay()
     torch.cuda.synchronize(dev)
     assert torch.all(buf == 1)
+
+
+def test_use_batch_norm_flag_keeps_the_reference_quirk(pkg, dev):
+    """--use_batch_norm True (homography_model.py:92-93,356): slim.batch_norm(out, self.is_training) passes is_training as the DECAY,
+    so the moving statistics never move (decay 1 in train mode; their update ops are never run either) -- training normalises with
+    batch statistics, test mode with the initial mean 0 / variance 1.  The mirror keeps that: momentum 0, centre only (no scale),
+    eps 1e-3, BN after the ReLU; the fused epilogues step aside for the torch ops."""
+    hm, synthetic, drv = pkg
+    args = drv.build_parser().parse_args(['--batch_size', str(B), '--img_h', str(H), '--img_w', str(W), '--patch_size', str(P),
+                                          '--rho', str(RHO), '--use_batch_norm', 'True'])
+    assert args.use_batch_norm is True
+    torch.manual_seed(0)
+    step = drv.TrainStep(args, dev, world=1)
+    net = step.net
+    assert net.use_batch_norm and len(net.bns) == 8 and all(not bn.weight.requires_grad and bn.bias.requires_grad for bn in net.bns)
+    batch = synthetic.make_batch(B, H, W, P, RHO, seed=8, device=dev)
+    losses = [float(step(batch).l1_loss.detach()) for _ in range(5)]
+    assert np.isfinite(losses).all()
+    for bn in net.bns:                                          # decay = 1: the moving statistics are still the initial ones
+        assert float(bn.running_mean.abs().max()) == 0.0 and float((bn.running_var - 1).abs().max()) == 0.0
+        assert float(bn.bias.grad.abs().max()) > 0              # beta trains
+    x = torch.cat([batch['I1_aug'], batch['I2_aug']], 3)
+    with torch.no_grad():
+        net.train(); torch.manual_seed(1); y_train = net(x)
+        net.eval(); y_test = net(x)
+        net.train()
+    assert torch.isfinite(y_test).all() and float((y_train - y_test).abs().max()) > 1e-3      # batch statistics vs none
+    res = drv.TestHomography(args, step_fn=step).run()
+    assert res['mean_corner_error'] > 0
