@@ -130,3 +130,42 @@ def test_epilogue_argument_errors(lib, dev):
     assert lib.uh_bias_relu_backward(one, one, one, one, None, 0, 16, 64, None) == -4
     assert lib.uh_bias_relu_pool_forward(one, one, one, one, 1, 3, 4, 64, None) == -2
     assert lib.uh_bias_relu_pool_backward(None, one, one, one, one, 1 << 20, 1, 4, 4, 64, None) == -1
+
+
+def test_fuzz_epilogues_random_shapes(lib, dev):
+    """40 random shapes per kernel pair (channel counts from the accepted set, pixel counts that end anywhere inside a chunk, odd
+    batch sizes), random data with ties: forward bits and backward routing against torch on every element."""
+    from unsuperviseddeephomographyral2018_amd import _lib
+    rs = __import__('numpy').random.RandomState(11)
+    chans = [4, 8, 16, 32, 64, 128, 256]
+    for it in range(40):
+        Cc = int(chans[rs.randint(len(chans))])
+        g = torch.Generator(device=dev).manual_seed(1000 + it)
+        # ---- bias + ReLU
+        npix = int(rs.randint(1, 3000))
+        y0 = _tied((npix, Cc), g, dev, levels=4); bias = _tied((Cc,), g, dev, levels=2)
+        gy = torch.randn(npix, Cc, generator=g, device=dev)
+        y = y0.clone(); mask = torch.empty(lib.uh_relu_mask_bytes(npix, Cc), dtype=torch.uint8, device=dev)
+        _lib.check(lib.uh_bias_relu_forward(_p(y), _p(bias), _p(mask), npix, Cc, _stream()), 'fwd')
+        ref = F.relu(y0 + bias)
+        assert torch.equal(y, ref), (it, npix, Cc)
+        nws = lib.uh_bias_relu_backward_workspace_bytes(npix, Cc)
+        ws = torch.empty(nws // 4, device=dev); gout = torch.empty_like(gy); db = torch.empty(Cc, device=dev)
+        _lib.check(lib.uh_bias_relu_backward(_p(mask), _p(gy), _p(gout), _p(db), _p(ws), nws, npix, Cc, _stream()), 'bwd')
+        want = torch.where(ref > 0, gy, torch.zeros_like(gy))
+        assert torch.equal(gout, want), (it, npix, Cc)
+        assert float((db.double() - want.double().sum(0)).abs().max()) <= 1e-5 * max(1.0, float(want.abs().sum(0).max()))
+        # ---- bias + ReLU + pool
+        N, Hh, Ww = int(rs.randint(1, 6)), 2 * int(rs.randint(1, 12)), 2 * int(rs.randint(1, 12))
+        y0 = _tied((N, Hh, Ww, Cc), g, dev, levels=3); gp = torch.randn(N, Hh // 2, Ww // 2, Cc, generator=g, device=dev)
+        a = (y0 + bias).permute(0, 3, 1, 2).clamp_min(0).detach().requires_grad_(True)
+        pr = F.max_pool2d(a, 2, 2); pr.backward(gp.permute(0, 3, 1, 2))
+        g_ref = (a.grad * (a.detach() > 0)).permute(0, 2, 3, 1).contiguous()
+        pooled = torch.empty(N, Hh // 2, Ww // 2, Cc, device=dev)
+        mask = torch.empty(lib.uh_pool_mask_bytes(N, Hh, Ww, Cc), dtype=torch.uint8, device=dev)
+        _lib.check(lib.uh_bias_relu_pool_forward(_p(y0), _p(bias), _p(pooled), _p(mask), N, Hh, Ww, Cc, _stream()), 'pool fwd')
+        assert torch.equal(pooled, pr.detach().permute(0, 2, 3, 1)), (it, N, Hh, Ww, Cc)
+        nws = lib.uh_bias_relu_pool_backward_workspace_bytes(N, Hh, Ww, Cc)
+        ws = torch.empty(nws // 4, device=dev); gout = torch.empty(N, Hh, Ww, Cc, device=dev); db = torch.empty(Cc, device=dev)
+        _lib.check(lib.uh_bias_relu_pool_backward(_p(mask), _p(gp), _p(gout), _p(db), _p(ws), nws, N, Hh, Ww, Cc, _stream()), 'pool bwd')
+        assert torch.equal(gout, g_ref), (it, N, Hh, Ww, Cc)
