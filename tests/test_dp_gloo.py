@@ -350,3 +350,60 @@ def test_tunableop_cache_dir_must_be_private(tmp_path, monkeypatch):
     assert D._private_dir_or_fresh(str(link)) != str(link)                # lstat: a symlink is not a directory of ours
     monkeypatch.setattr(os, 'getuid', lambda: os.stat(str(good)).st_uid + 1)
     assert D._private_dir_or_fresh(str(good)) != str(good)                # owned by another user
+
+
+def _worker_monitors(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from unsuperviseddeephomographyral2018_amd import dist as D
+    D.init_from_env(backend='gloo')
+    calls = []
+    real = torch.distributed.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(int(t.numel()))
+        return real(t, *a, **k)
+    torch.distributed.all_reduce = counting
+    mon = D.TowerMonitors(3, world, torch.device('cpu'))
+    logs = []
+    for step in range(25):
+        vals = [torch.tensor(float(10 * rank + step)), torch.tensor(float(step) * 0.5), torch.tensor(1.0 + rank)]
+        if step == 7 and rank == 1:
+            vals[1] = torch.tensor(float('nan'))                 # one tower's value is non-finite at one step
+        mon.add(vals)
+        if step % 10 == 0:
+            logs.append((step, mon.reduce(extra_count=rank + 1)))
+    q.put((rank, calls, logs, mon.collectives))
+    torch.distributed.destroy_process_group()
+
+
+def test_tower_monitors_reduce_at_log_steps_only():
+    """dist.TowerMonitors (what train() logs with; reference :279-284,333-352): 25 steps on two ranks with a log line
+    every 10 -> exactly three collectives of 2 k + 2 values, never one per step; the means are the per-step means over towers
+    since the start / since the previous line; a non-finite value is left out and counted; the extra counter is summed."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_monitors, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    for rank, calls, logs, ncoll in out:
+        assert calls == [8, 8, 8] and ncoll == 3                 # 2 * 3 + 2 values, at steps 0, 10, 20 only
+        assert [s for s, _ in logs] == [0, 10, 20]
+        assert all(l['extra'] == 3 for _, l in logs)             # 1 + 2 over the ranks, each time
+    logs = out[0][2]
+    assert out[0][2] == out[1][2]                                # every rank holds the same reduced figures
+    # first scalar: mean over towers of (10 r + step) = 5 + step; running mean over steps 0..s, window mean over the last window
+    s0, s10, s20 = (l for _, l in logs)
+    assert s0['win_n'] == 1 and s10['win_n'] == 10 and s20['win_n'] == 10
+    np.testing.assert_allclose(s10['avg'][0], 5 + np.mean(range(11)), rtol=1e-6)
+    np.testing.assert_allclose(s10['win'][0], 5 + np.mean(range(1, 11)), rtol=1e-6)
+    np.testing.assert_allclose(s20['win'][0], 5 + np.mean(range(11, 21)), rtol=1e-6)
+    np.testing.assert_allclose(s20['avg'][2], 1.5, rtol=1e-6)
+    # second scalar: rank 1's step-7 value was NaN -> left out of the sums (counted once), the window mean is over 2 x 10 slots
+    assert s0['nonfinite'] == 0 and s10['nonfinite'] == 1 and s20['nonfinite'] == 1
+    np.testing.assert_allclose(s10['win'][1], (2 * sum(0.5 * s for s in range(1, 11)) - 3.5) / 20, rtol=1e-6)

@@ -390,6 +390,50 @@ def broadcast_state(module_and_optimizer, src=0):
     return n
 
 
+class TowerMonitors(object):
+    """Running means of a tower's logging scalars with ONE collective per log line (reference: total_*_loss = reduce_mean over
+    towers, homography_CNN_synthetic.py:279-284, accumulated and printed every 100 steps, :333-352; SURVEY 8e "loss scalars
+    all-reduced only for logging").  Every rank adds its tower's values to device-side sums each step -- no collective, no host
+    sync; at a log step the sums of all ranks meet in one all-reduce of 2 k + 2 doubles.  Means are linear, so the printed
+    figures equal the per-step mean over towers.  A non-finite value (a degenerate pair makes that step's loss NaN; its gradient
+    is zeroed in the DLT backward) is kept out of the sums and counted."""
+
+    def __init__(self, k, world, device):
+        self.k, self.world = int(k), int(world)
+        self.totals = torch.zeros(self.k, device=device)
+        self.window = torch.zeros(self.k, device=device)
+        self.nonfinite = torch.zeros((), device=device)
+        self.steps = 0
+        self.win_n = 0
+        self.collectives = 0
+
+    def add(self, values):
+        cur = torch.stack([v.detach().float().reshape(()) for v in values])
+        finite = torch.isfinite(cur)
+        self.nonfinite += (~finite.all()).float()
+        cur = torch.where(finite, cur, torch.zeros_like(cur))
+        self.totals += cur
+        self.window += cur
+        self.steps += 1
+        self.win_n += 1
+
+    def reduce(self, extra_count=0):
+        """Collective (every rank, same step).  -> dict(avg = means since the start, win = means since the previous call, win_n,
+        nonfinite = tower-steps with a non-finite value so far, extra = sum over ranks of `extra_count`); starts a new window."""
+        mon = torch.cat([self.totals, self.window, self.nonfinite.reshape(1),
+                         torch.tensor([float(extra_count)], device=self.totals.device)]).double()
+        if self.world > 1:
+            dist.all_reduce(mon)
+            self.collectives += 1
+        k = self.k
+        out = {'avg': (mon[:k] / (self.world * max(self.steps, 1))).tolist(),
+               'win': (mon[k:2 * k] / (self.world * max(self.win_n, 1))).tolist(), 'win_n': self.win_n,
+               'nonfinite': int(round(float(mon[2 * k]))), 'extra': int(round(float(mon[2 * k + 1])))}
+        self.window.zero_()
+        self.win_n = 0
+        return out
+
+
 def all_reduce_mean_scalars(values, world):
     """Mean over ranks of a few logging scalars (total_*_loss = reduce_mean over towers, :279-284)."""
     if world == 1:

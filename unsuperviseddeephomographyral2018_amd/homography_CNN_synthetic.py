@@ -395,7 +395,6 @@ def train(args):
         print('===> Start step:', start_step, ' world size:', world)
     B_local = args.batch_size // world
     names = ['h_loss', 'rec_loss', 'ssim_loss', 'l1_loss', 'l1_smooth_loss', 'ncc_loss']
-    totals = torch.zeros(len(names), device=device)
     batch = None
     disk = None
     if args.data_path:
@@ -421,9 +420,7 @@ def train(args):
                                                                seed=args.seed + rank, device=device, kind=args.texture))
         if rank == 0:
             print('===> conv find pass (rank 0 first, then the others): %.1f s' % t_find, flush=True)
-    window = torch.zeros(len(names), device=device)
-    win_n = 0
-    nonfinite_steps = torch.zeros((), device=device)
+    monitors = uh_dist.TowerMonitors(len(names), world, device)
     from . import _lib
     _lib.dlt_zeroed_pairs(reset=True)
     zeroed_pairs = 0
@@ -441,38 +438,23 @@ def train(args):
                 batch = synthetic.make_batch(B_local, args.img_h, args.img_w, args.patch_size, args.rho,
                                              seed=args.seed + step * world + rank, device=device, kind=args.texture)
             model = step_fn(batch)
-            # Monitors (:333-352): each rank keeps running sums of ITS tower's six loss values on its device -- no collective and no
-            # host sync in the hot loop.  They meet at LOG steps only (total_*_loss = reduce_mean over towers, :279-284; SURVEY
-            # 8e "loss scalars all-reduced only for logging"): one all-reduce of 14 floats + the zeroed-pair count every
-            # --log_every steps.  Means are linear, so the printed figures equal a per-step mean over towers.
-            cur = torch.stack([getattr(model, n).detach().float().reshape(()) for n in names])
-            finite = torch.isfinite(cur)
-            nonfinite_steps += (~finite.all()).float()          # a degenerate pair makes that step's loss VALUE NaN (its gradient is
-            cur = torch.where(finite, cur, torch.zeros_like(cur))   # zeroed in the DLT backward): keep it out of the running means
-            totals += cur
-            window += cur
-            win_n += 1
+            # Monitors (:333-352): per-rank running sums on the device, ONE collective per log line (dist.TowerMonitors)
+            monitors.add([getattr(model, n) for n in names])
             if step % args.log_every == 0:
                 z = _lib.dlt_zeroed_pairs(reset=True)            # (synchronous read of a device counter: log time only)
-                mon = torch.cat([totals, window, nonfinite_steps.reshape(1), torch.tensor([float(z)], device=device)]).double()
-                if world > 1:                                    # the ONE logging collective: sums over ranks
-                    torch.distributed.all_reduce(mon)
-                k = len(names)
-                zeroed_pairs += int(round(float(mon[2 * k + 1])))
+                mon = monitors.reduce(extra_count=z)
+                zeroed_pairs += mon['extra']
                 if rank == 0:
                     n = step - start_step + 1
-                    avg = (mon[:k] / (world * n)).tolist()           # running means since the start, as the reference prints (:345-352)
-                    win = (mon[k:2 * k] / (world * win_n)).tolist()  # ... and the mean over the steps since the previous log line
-                    nf = int(round(float(mon[2 * k])))
-                    dt = time.time() - t0
+                    avg, win = mon['avg'], mon['win']            # running means since the start, as the reference prints (:345-352),
+                    dt = time.time() - t0                        # and the mean over the steps since the previous log line
                     print('Train: step %d  ' % step + ', '.join('%s %.6f' % (kk, v) for kk, v in zip(names, avg))
                           + ', lr %.6f, %.1f pairs/s' % (step_fn.learning_rate(), n * args.batch_size / max(dt, 1e-9))
-                          + '  | last %d steps: h_loss %.4f %s %.6f' % (win_n, win[0], args.loss_type, win[names.index(args.loss_type)])
-                          + ('  | %d tower-steps with a non-finite loss value so far' % nf if nf else '')
+                          + '  | last %d steps: h_loss %.4f %s %.6f' % (mon['win_n'], win[0], args.loss_type, win[names.index(args.loss_type)])
+                          + ('  | %d tower-steps with a non-finite loss value so far' % mon['nonfinite'] if mon['nonfinite'] else '')
                           + ('  | %d pairs had a non-finite gradient zeroed so far (--zero_nonfinite_grad; the reference would have '
                              'propagated NaN)' % zeroed_pairs if zeroed_pairs else ''),
                           flush=True)
-                window.zero_(); win_n = 0
             if rank == 0 and step and step % args.save_every == 0:
                 os.makedirs(ckpt_dir, exist_ok=True)
                 torch.save(step_fn.state_dict(), ckpt)
