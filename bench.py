@@ -24,7 +24,10 @@ Rank 0 prints ONE JSON line; extra objects:
                   copied to the host (rank 0, N=1 only).
   exchange     -- N > 1 only (dist.exchange_report): each bucket's stand-alone all-reduce time with busbw against (n - 1) x 153 GB/s
                   of xGMI, ms_per_step_no_exchange (10 more steps with the averager disabled on every rank) and
-                  exchange_cost_ms_per_step = ms_per_step - that: what the gradient exchange really costs, contention included.
+                  exchange_cost_ms_per_step = ms_per_step - that: what the gradient exchange really costs, contention included;
+                  the ranks are put back in step afterwards (resynced_tensors).
+  headline_roofline -- the whole step against the f32 MFMA peak (the conv stack is stock MIOpen); hot_path_share_of_step = the
+                  library kernels timed in this run (avg_us x launches / steps) over ms_per_step -- computed, never quoted.
   quality      -- the metric's second half, "mean corner error": a from-scratch unsupervised l1_loss training with the
                   reference's hyper-parameters for a fixed step budget OUTSIDE the timed region, then the reference's
                   test statistics (homography_CNN_synthetic.py:391-401,573-579) on held-out pairs (rank 0, N=1 only).
