@@ -58,9 +58,20 @@ def _diff(a, b):
     return worst, (num / max(den, 1e-300)) ** 0.5
 
 
+def _private_miopen_db():
+    """These comparisons need MIOpen's deterministic solvers.  In immediate mode (cudnn.benchmark off) MIOpen still consults the
+    USER find-db: entries left there by an earlier process that ran the same conv shapes with find mode on (the trainer tests
+    of this file do, at the same per-tower batch) make it pick the recorded fastest solver -- split-K with atomics -- and one
+    gradient computed twice then differs in the last bits.  A fresh box has no such entries; a box that already ran the suite
+    does.  An empty private user db per worker process makes both behave like the fresh box."""
+    import tempfile
+    os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='uh_miopen_db_')
+
+
 def _worker(rank, world, port, q, loss_type, dropout_p):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    _private_miopen_db()
     import copy
     from unsuperviseddeephomographyral2018_amd import _lib, dist as D, synthetic
     from unsuperviseddeephomographyral2018_amd.homography_CNN_synthetic import TrainStep, tf_adam_eps
@@ -220,6 +231,7 @@ def _rccl_worker(q, port):
     """ONE rank, backend "nccl" (= RCCL): the collectives are identities, the CODE PATH is the multi-GPU one."""
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', LOCAL_WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    _private_miopen_db()
     import copy
     import torch.distributed as dist
     from unsuperviseddeephomographyral2018_amd import _lib, dist as D, synthetic
