@@ -66,6 +66,28 @@ def _private_miopen_db():
     does.  An empty private user db per worker process makes both behave like the fresh box."""
     import tempfile
     os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='uh_miopen_db_')
+    # ... and the deterministic route needs MIOpen's reference solvers: a trainer that ran in the PARENT pytest process
+    # (dist.skip_naive_conv_in_find: MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_*=0, inherited by spawned workers) leaves it with
+    # "No suitable algorithm was found" for the 2-channel first layer
+    for k in [k for k in os.environ if k.startswith('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_')]:
+        del os.environ[k]
+
+
+def _collect(q, procs, n, timeout):
+    """n results from the workers' queue -- failing as soon as a worker has died instead of waiting out the whole timeout."""
+    import queue as _queue
+    import time as _time
+    out, t0 = [], _time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=2))
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead:
+                raise AssertionError('a worker process died (exit codes %r) before reporting' % dead)
+            if _time.time() - t0 > timeout:
+                raise AssertionError('workers did not report within %d s' % timeout)
+    return out
 
 
 def _worker(rank, world, port, q, loss_type, dropout_p):
@@ -178,7 +200,7 @@ def _run(loss_type, dropout_p):
     for p in procs:
         p.start()
     try:
-        out = sorted([q.get(timeout=600) for _ in range(world)], key=lambda o: o['rank'])
+        out = sorted(_collect(q, procs, world, 600), key=lambda o: o['rank'])
     finally:
         for p in procs:
             p.join(timeout=120)
@@ -297,7 +319,7 @@ def test_product_step_over_rccl_one_rank_equals_plain_step():
     p = ctx.Process(target=_rccl_worker, args=(q, _free_port()))
     p.start()
     try:
-        out = q.get(timeout=600)
+        out = _collect(q, [p], 1, 600)[0]
     finally:
         p.join(timeout=120)
         if p.is_alive():
@@ -355,7 +377,7 @@ def test_train_two_ranks_reduces_its_monitors_at_log_steps_only(tmp_path):
     for p in procs:
         p.start()
     try:
-        out = sorted([q.get(timeout=900) for _ in range(world)], key=lambda o: o['rank'])
+        out = sorted(_collect(q, procs, world, 900), key=lambda o: o['rank'])
     finally:
         for p in procs:
             p.join(timeout=120)
