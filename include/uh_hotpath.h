@@ -29,7 +29,9 @@
  *
  * Conventions
  *   - every `const float*` / `float*` / `const int*` below is a DEVICE pointer owned by the caller,
- *     contiguous, row-major, 4-byte aligned, unless the comment says HOST.  Images are NHWC.
+ *     contiguous, row-major, 4-byte aligned, unless the comment says HOST.  Images are NHWC.  The conv
+ *     epilogues and uh_prepare_inputs move 16 bytes per lane: give them 16-byte aligned tensors (any
+ *     hipMalloc / torch allocation is 256-byte aligned).
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
  *     stream) and returns; nothing allocates or frees device memory.  The calls that SYNCHRONISE are
  *     exactly two, both host-side read-backs: uh_dlt_zeroed_pairs (waits for `stream`) and
